@@ -1,0 +1,149 @@
+'use strict';
+/*
+ * ref_harness.js — TEST INFRASTRUCTURE.  Runs the UNMODIFIED reference bundle (/root/reference/headtrackr.js,
+ * or $HT_REFERENCE_JS) on top of oracle/canvas_shim.js and dumps golden vectors as JSON.
+ *
+ *   node oracle/ref_harness.js job.json out.json
+ *
+ * job.json: { "cases": [ {name, kind, w, h, ...} ] } with raw RGBA frames in files (see tests/golden/make_golden.py).
+ *   kind "detect":     {frame, interval?, ops:["gray","pyramid","raw","grouped","whitebalance"]}
+ *                      gray/pyramid = CRC32 of byte 0 of every pixel of each pyramid canvas, in creation order
+ *                      (ccv.js:117-147: levels 1..5, levels 6..38, then for i=12..38 variants 1,2,3)
+ *   kind "camshift":   {frames:[...], rect:[x,y,w,h], calcAngles} -> per track() call searchWindow + trackObj
+ *   kind "facetrackr": {frames:[...], params:{...}} -> per track() call the tracking object
+ * Only this file and tests/golden/make_golden.py touch the reference; nothing here ships with the product.
+ */
+const fs = require('fs');
+const path = require('path');
+const shim = require('./canvas_shim.js');
+
+const refPath = process.env.HT_REFERENCE_JS || '/root/reference/headtrackr.js';
+global.document = shim.makeDocument();
+global.window = global;                       /* the bundle's UMD wrapper falls back to `this`/window */
+const headtrackr = require(refPath);
+
+const CRC_TABLE = (function () {
+  const t = new Int32Array(256);
+  for (let n = 0; n < 256; n++) {
+    let c = n;
+    for (let k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320 ^ (c >>> 1)) : (c >>> 1);
+    t[n] = c;
+  }
+  return t;
+})();
+function crc32Channel0(buf) {             /* CRC32 (zlib polynomial) over byte 0 of every RGBA pixel */
+  let c = -1;
+  for (let i = 0; i < buf.length; i += 4) c = CRC_TABLE[(c ^ buf[i]) & 0xFF] ^ (c >>> 8);
+  return (c ^ -1) >>> 0;
+}
+function crc32All(buf) {
+  let c = -1;
+  for (let i = 0; i < buf.length; i++) c = CRC_TABLE[(c ^ buf[i]) & 0xFF] ^ (c >>> 8);
+  return (c ^ -1) >>> 0;
+}
+
+function loadCanvas(file, w, h) {
+  const bytes = fs.readFileSync(file);
+  if (bytes.length !== w * h * 4) throw new Error(file + ': expected ' + (w * h * 4) + ' bytes, got ' + bytes.length);
+  return new shim.Canvas(w, h).loadRGBA(bytes);
+}
+function copyCanvas(c) {
+  const d = new shim.Canvas(c.width, c.height);
+  d._buf.set(c._buf);
+  return d;
+}
+function rectOut(r) {
+  const o = { x: r.x, y: r.y, width: r.width, height: r.height, confidence: r.confidence };
+  if (r.neighbors !== undefined) o.neighbors = r.neighbors;
+  if (r.neighbor !== undefined) o.neighbor = r.neighbor;
+  return o;
+}
+
+function runDetect(cs, base) {
+  const out = { name: cs.name, kind: 'detect', w: cs.w, h: cs.h };
+  const interval = cs.interval === undefined ? 5 : cs.interval;
+  const ops = cs.ops || ['gray', 'pyramid', 'raw', 'grouped'];
+  const input = loadCanvas(path.resolve(base, cs.frame), cs.w, cs.h);
+  out.input_crc = crc32All(input._buf);
+  if (ops.indexOf('whitebalance') >= 0) out.whitebalance = headtrackr.getWhitebalance(input);
+  const gray = headtrackr.ccv.grayscale(copyCanvas(input));
+  if (ops.indexOf('gray') >= 0) {
+    out.gray_crc = crc32Channel0(gray._buf);
+    out.gray_rgba_crc = crc32All(gray._buf);
+  }
+  if (ops.indexOf('raw') >= 0 || ops.indexOf('pyramid') >= 0) {
+    shim.stats.trackCreated = true; shim.stats.created = [];
+    const seq = headtrackr.ccv.detect_objects(copyCanvas(gray), headtrackr.cascade, interval, 0);
+    shim.stats.trackCreated = false;
+    if (ops.indexOf('pyramid') >= 0) {
+      out.pyramid = shim.stats.created.map(function (c) { return { w: c.width, h: c.height, crc: crc32Channel0(c._buf) }; });
+    }
+    shim.stats.created = [];
+    if (ops.indexOf('raw') >= 0) out.raw = seq.map(rectOut);
+  }
+  if (ops.indexOf('grouped') >= 0) {
+    const mn = cs.min_neighbors === undefined ? 1 : cs.min_neighbors;
+    out.min_neighbors = mn;
+    out.grouped = headtrackr.ccv.detect_objects(copyCanvas(gray), headtrackr.cascade, interval, mn).map(rectOut);
+  }
+  return out;
+}
+
+function runCamshift(cs, base) {
+  const out = { name: cs.name, kind: 'camshift', w: cs.w, h: cs.h, rect: cs.rect, calcAngles: cs.calcAngles !== false, calls: [] };
+  const tr = new headtrackr.camshift.Tracker({ calcAngles: cs.calcAngles !== false });
+  const first = loadCanvas(path.resolve(base, cs.frames[0]), cs.w, cs.h);
+  tr.initTracker(first, new headtrackr.camshift.Rectangle(cs.rect[0], cs.rect[1], cs.rect[2], cs.rect[3]));
+  const start = cs.track_first ? 0 : 1;   /* track_first: also track on the init frame */
+  for (let i = start; i < cs.frames.length; i++) {
+    const c = loadCanvas(path.resolve(base, cs.frames[i]), cs.w, cs.h);
+    const reps = cs.repeat || 1;
+    for (let r = 0; r < reps; r++) {
+      tr.track(c);
+      const sw = tr.getSearchWindow(), to = tr.getTrackObj();
+      out.calls.push({ frame: i, sw: [sw.x, sw.y, sw.width, sw.height], x: to.x, y: to.y, width: to.width, height: to.height, angle: to.angle });
+    }
+  }
+  return out;
+}
+
+function runFacetrackr(cs, base) {
+  const out = { name: cs.name, kind: 'facetrackr', w: cs.w, h: cs.h, params: cs.params || {}, calls: [] };
+  const params = Object.assign({}, cs.params || {});
+  const events = [];
+  const listener = function (e) { events.push({ x: e.x, y: e.y, width: e.width, height: e.height, angle: e.angle, confidence: e.confidence, detection: e.detection }); };
+  document.addEventListener('facetrackingEvent', listener);
+  const canvas = new shim.Canvas(cs.w, cs.h);
+  const ft = new headtrackr.facetrackr.Tracker(params);
+  ft.init(canvas);
+  for (let i = 0; i < cs.frames.length; i++) {
+    canvas.loadRGBA(fs.readFileSync(path.resolve(base, cs.frames[i])));
+    ft.track();
+    const t = ft.getTrackingObject();
+    out.calls.push({ frame: i, x: t.x, y: t.y, width: t.width, height: t.height, angle: t.angle, confidence: t.confidence, detection: t.detection });
+  }
+  document.removeEventListener('facetrackingEvent', listener);
+  out.events = events;
+  return out;
+}
+
+function main() {
+  const jobFile = process.argv[2], outFile = process.argv[3];
+  const job = JSON.parse(fs.readFileSync(jobFile, 'utf8'));
+  const base = path.dirname(path.resolve(jobFile));
+  const res = { reference_rev: headtrackr.rev, node: process.version, scale6: Math.pow(2, 1 / 6),
+    scale6_pows: [0, 1, 2, 3, 4, 5].map(function (i) { return Math.pow(Math.pow(2, 1 / 6), i); }), cases: [] };
+  job.cases.forEach(function (cs) {
+    const t0 = process.hrtime.bigint();
+    let r;
+    if (cs.kind === 'detect') r = runDetect(cs, base);
+    else if (cs.kind === 'camshift') r = runCamshift(cs, base);
+    else if (cs.kind === 'facetrackr') r = runFacetrackr(cs, base);
+    else throw new Error('unknown case kind ' + cs.kind);
+    r.gen = cs.gen;                         /* how make_golden.py synthesised the input (echoed for the tests) */
+    res.cases.push(r);
+    process.stderr.write(cs.name + ': ' + Number((process.hrtime.bigint() - t0) / 1000000n) + ' ms\n');
+  });
+  fs.writeFileSync(outFile, JSON.stringify(res));
+}
+main();

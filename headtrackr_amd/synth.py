@@ -172,3 +172,44 @@ def mixed_batch(n: int, w: int, h: int, seed0: int = 1234) -> np.ndarray:
         else:
             out[i] = face_frame(w, h, seeded_faces(w, h, seed))
     return out
+
+
+def blob_frame(w: int, h: int, cx: int, cy: int, a: int, b: int, rot=(1, 0, 1), color=(200, 60, 40), seed: int = 7,
+               bg: str = "noise") -> np.ndarray:
+    """Camshift target: a filled ellipse (semi-axes a, b; rotation given as integer (cos_num, sin_num, den), e.g.
+    (4, 3, 5)) of a saturated colour with +-7 per-channel seeded jitter, on a noise or flat-gray background."""
+    out = noise_frame(w, h, seed) if bg == "noise" else face_frame(w, h, [], gray=110)
+    cn, sn, den = rot
+    x = np.arange(w, dtype=np.int64)[None, :] - cx
+    y = np.arange(h, dtype=np.int64)[:, None] - cy
+    u = x * cn + y * sn      # scaled by den
+    v = -x * sn + y * cn
+    inside = (u * u) * (b * b) + (v * v) * (a * a) <= (a * a) * (b * b) * (den * den)
+    jit = (lcg_stream(seed + 977, 3 * w * h) >> np.uint32(28)).astype(np.int64).reshape(h, w, 3) - 8  # -8..7
+    for c in range(3):
+        ch = out[..., c].astype(np.int64)
+        ch = np.where(inside, np.clip(color[c] + jit[..., c], 0, 255), ch)
+        out[..., c] = ch.astype(np.uint8)
+    return out
+
+
+def make(gen: dict, w: int, h: int) -> np.ndarray:
+    """Build a frame from a generator spec (the specs are stored in tests/golden/*.json next to the expected output)."""
+    fam = gen["family"]
+    if fam == "noise":
+        return noise_frame(w, h, int(gen["seed"]))
+    if fam == "smooth":
+        return smooth_frame(w, h, int(gen["seed"]))
+    if fam == "face":
+        return face_frame(w, h, gen["faces"], gray=int(gen.get("gray", 110)))
+    if fam == "blob":
+        return blob_frame(w, h, int(gen["cx"]), int(gen["cy"]), int(gen["a"]), int(gen["b"]), tuple(gen.get("rot", (1, 0, 1))),
+                          tuple(gen.get("color", (200, 60, 40))), int(gen.get("seed", 7)), gen.get("bg", "noise"))
+    if fam == "mixed":
+        i = int(gen["index"]); seed = int(gen.get("seed0", 1234)) + i
+        if i % 3 == 0:
+            return noise_frame(w, h, seed)
+        if i % 3 == 1:
+            return smooth_frame(w, h, seed)
+        return face_frame(w, h, seeded_faces(w, h, seed))
+    raise ValueError(f"unknown frame family {fam!r}")

@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the detect(+camshift) hot path on N MI355X, one JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
+gray -> 39-level pyramid -> full BBF cascade scan -> raw hits copied back and sorted (ht_detect_enqueue +
+ht_detect_collect), plus, for N > 1, one RCCL all-gather of the fixed-size per-frame best-face records.
+Workloads (BASELINE.json configs): c2 = 256 x 320x240 detect on every GPU (default; the configuration the metric is
+quoted on), c4 = 128 x 1280x720 per GPU detect (1024 frames on 8 GPUs), c3 = c2's frames, detect once + 60 camshift
+track() calls per step.  Weak scaling: per-GPU work is fixed, value = all ranks' frames / max-over-ranks time.
+
+Extra objects on the line: "roofline" (dominant kernel, HBM bound, live HIP-event timing through the C ABI's
+profiling scopes on the same stream) and "cpu_baseline" (the CPU oracle port, 1 core, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: 256 for c2/c3, 128 for c4)")
+    ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames generated (tiled to --frames)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
+    return ap.parse_args()
+
+
+def best_face_records(hits, counts, nframes):
+    """fixed-size per-frame record that is all-gathered: [count, scale, q, x, y, confidence] of the best raw hit"""
+    rec = np.zeros((nframes, 8), dtype=np.float64)
+    k = 0
+    for f in range(nframes):
+        c = int(counts[f])
+        if c:
+            h = hits[k : k + c]
+            b = h[np.argmax(h["sum"])]
+            rec[f, :6] = (c, b["scale"], b["q"], b["x"], b["y"], b["sum"])
+        k += c
+    return rec
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from headtrackr_amd import synth
+    from headtrackr_amd.api import Context
+
+    if a.workload == "c4":
+        W, H, nf = 1280, 720, a.frames or 128
+        uniq = a.unique or 12
+    else:
+        W, H, nf = 320, 240, a.frames or 256
+        uniq = a.unique or nf
+    uniq = min(uniq, nf)
+    # frame i of rank r is synthetic frame (r*nf + i) mod uniq of the N/S/F mix
+    base = synth.mixed_batch(uniq, W, H, seed0=1234 + 1000 * rank)
+    frames = base[np.arange(nf) % uniq]
+    dev = torch.from_numpy(frames).cuda()  # resident in HBM before the timed region
+    stream = torch.cuda.current_stream()
+    ctx = Context(device=local, stream=stream.cuda_stream)
+    ctx.set_geometry(W, H, nf)
+    ctx.bind_device(dev.data_ptr(), nf, W * H * 4)
+    if a.workload == "c3":
+        ctx.camshift_reserve(nf)
+
+    rec_local = torch.zeros((nf, 8), dtype=torch.float64, device="cuda")
+    rec_all = torch.zeros((world * nf, 8), dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def step():
+        ctx.detect_enqueue(a.flags)
+        hits, counts = ctx.detect_collect(cap=1 << 18)
+        if a.workload == "c3":
+            # detect once, then 60 camshift track() calls on the (static) batch, SURVEY.md §8 C3
+            starts = np.concatenate([[0], np.cumsum(counts)])
+            rects = []
+            for f in range(nf):
+                if counts[f]:
+                    r = ctx.group_rects(ctx.hits_to_rects(hits[starts[f] : starts[f + 1]]), 1)
+                    b = r[np.argmax(r["confidence"])]
+                    rects.append((int(np.floor(b["x"])), int(np.floor(b["y"])), int(np.floor(b["width"])), int(np.floor(b["height"]))))
+                else:
+                    rects.append((W // 4, H // 4, W // 2, H // 2))
+            ctx.camshift_init(rects)
+            for it in range(60):
+                ctx.camshift_track(nf, calc_angles=True, fetch=(it == 59))
+        if world > 1:
+            rec_local.copy_(torch.from_numpy(best_face_records(hits, counts, nf)), non_blocking=False)
+            dist.all_gather_into_tensor(rec_all, rec_local)
+        return hits, counts
+
+    for _ in range(a.warmup):
+        hits, counts = step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        hits, counts = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_frames = world * nf * a.steps
+    fps = total_frames / dt
+
+    # ---- roofline of the dominant kernel: live HIP-event timing on the ctx stream (rank 0) ----------------------
+    roofline = None
+    extra = {}
+    if rank == 0:
+        ctx.profile(True)
+        ctx.kernel_times(reset=True)
+        psteps = max(3, min(10, a.steps))
+        for _ in range(psteps):
+            ctx.detect_enqueue(a.flags)
+            ctx.detect_collect(cap=1 << 18)
+        kt = ctx.kernel_times(reset=True)
+        ctx.profile(False)
+        per_step = {k: v["ms"] / psteps for k, v in kt.items()}
+        dom = max(per_step, key=per_step.get)
+        P = ctx.pyramid_bytes_per_frame
+        b_detect = 4 * W * H + 2 * P  # read RGBA once, write each gray plane once, read it once in the scan
+        launches_per_step = kt[dom]["launches"] / psteps
+        avg_launch_ms = kt[dom]["ms"] / kt[dom]["launches"]
+        achieved = b_detect * nf / launches_per_step / (avg_launch_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tf):
+            try:
+                traffic = json.load(open(tf)).get(a.workload, {}).get(dom)
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
+                        algorithmic_bytes_per_frame=b_detect, avg_launch_ms=round(avg_launch_ms, 5))
+        dev_ms = sum(per_step.values())
+        sc = ctx.stage_counts()
+        extra = dict(kernel_ms_per_step={k: round(v, 5) for k, v in per_step.items()},
+                     device_ms_per_step=round(dev_ms, 5),
+                     path_hbm_gbs=round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2),
+                     path_hbm_frac=round(b_detect * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     windows_per_frame=int(ctx.windows_per_frame),
+                     windows_per_s=round(float(sc[0]) / (dev_ms * 1e-3), 1),
+                     hits_per_step=int(len(hits)), stage_in=[int(v) for v in sc[:6]])
+
+    # ---- CPU baseline: the oracle port, single thread, bounded sample of the same frames (rank 0, N = 1 only) ------
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_seconds > 0:
+        from oracle import ht_oracle as ho
+
+        blob = ctx.cascade.blob
+        ho.detect_raw(frames[0], blob)  # warm
+        t0 = time.perf_counter()
+        done = 0
+        while done < nf and (done < 4 or time.perf_counter() - t0 < a.cpu_seconds):
+            ho.detect_raw(frames[done], blob)
+            done += 1
+        cdt = time.perf_counter() - t0
+        cpu = dict(value=round(done / cdt, 3), unit="frames/s", cores=1, kind="port",
+                   sample=f"first {done} of the {nf} {W}x{H} frames of this workload, oracle/ht_oracle.c detect (gray+pyramid+scan), 1 thread",
+                   host_cpus=os.cpu_count())
+
+    if rank == 0:
+        line = {
+            "metric": f"frames/sec full-cascade detect{'+60x camshift' if a.workload == 'c3' else ''} at {W}x{H}",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": {"c2": "C2: 256 x 320x240 RGBA frames per GPU, full BBF cascade detect (interval 5), raw hits to host",
+                                    "c3": "C3: 256 x 320x240 per GPU, detect once then 60 camshift track() calls",
+                                    "c4": "C4: 1280x720 frames, 128 per GPU (1024 on 8 GPUs), full cascade detect + all-gather of best-face records"}[a.workload],
+                       "frames_per_gpu": nf, "width": W, "height": H, "unique_frames": uniq, "frame_mix": "1/3 LCG noise, 1/3 smooth, 1/3 faces",
+                       "parallelism": f"frames sharded over {world} GPU(s), all-gather of {nf}x64B records" if world > 1 else "1 GPU"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        line.update(extra)
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

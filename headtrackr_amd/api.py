@@ -1,0 +1,200 @@
+"""Host-side Python mirror of the reference's per-frame interface, on top of the C ABI (include/headtrackr_hip.h).
+
+The primary host language of this project is JavaScript (headtrackr_amd/js/headtrackr.js over the N-API addon); this
+module exposes the same operations to Python so that the parity tests (pytest) and bench.py can drive the same C ABI.
+Names follow the reference: ccv.grayscale / ccv.detect_objects (src/ccv.js:22,109), camshift.Tracker
+(src/camshift.js:148), getWhitebalance (src/whitebalance.js:5).  Every method calls the HIP library; none computes on
+the CPU except ccv's own O(n^2) grouping of a few dozen rectangles, which the C ABI keeps on the host by design.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import native
+from .cascade import Cascade, load_cascade
+from .native import (HIT_DTYPE, HT_INPUT_GRAY_IN_R, HT_INPUT_RGBA, HT_SCAN_NO_SPLIT, HT_SCAN_SIMPLE, RECT_DTYPE,  # noqa: F401
+                     HtError)
+
+
+class Context:
+    """One ht_ctx: one GPU, one cascade, one stream."""
+
+    def __init__(self, cascade: Cascade | None = None, device: int = 0, interval: int = 5, stream: int | None = None,
+                 hit_capacity: int = 0, queue_capacity: int = 0):
+        self._lib = native.lib()
+        self.cascade = cascade or load_cascade()
+        cfg = native.Config(C.sizeof(native.Config), device, interval, hit_capacity, stream, queue_capacity, 0)
+        h = C.c_void_p()
+        blob = self.cascade.blob
+        st = self._lib.ht_create(C.byref(cfg), blob, len(blob), C.byref(h))
+        if st != 0:
+            raise HtError(st, self._lib.ht_last_error(None).decode())
+        self._h = h
+        self.interval = interval
+        self.width = self.height = 0
+        self.nframes = 0
+
+    # -- plumbing -------------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ht_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int, allow=()):
+        if st != 0 and st not in allow:
+            raise HtError(st, self._lib.ht_last_error(self._h).decode())
+        return st
+
+    # -- geometry / frames ------------------------------------------------------------------------------------
+    def set_geometry(self, width: int, height: int, max_batch: int, level_dims=None):
+        if level_dims is not None:
+            ld = np.ascontiguousarray(level_dims, dtype=np.int32).reshape(-1)
+            self._check(self._lib.ht_set_geometry(self._h, width, height, max_batch, ld.ctypes.data, ld.size // 2))
+        else:
+            self._check(self._lib.ht_set_geometry(self._h, width, height, max_batch, None, 0))
+        self.width, self.height = width, height
+
+    @property
+    def num_levels(self) -> int:
+        return self._lib.ht_num_levels(self._h)
+
+    @property
+    def windows_per_frame(self) -> int:
+        return self._lib.ht_windows_per_frame(self._h)
+
+    @property
+    def pyramid_bytes_per_frame(self) -> int:
+        return self._lib.ht_pyramid_bytes_per_frame(self._h)
+
+    def plane(self, level: int, slot: int = 0):
+        p = native.PlaneInfo()
+        self._check(self._lib.ht_plane(self._h, level, slot, C.byref(p)))
+        return p
+
+    def upload(self, frames: np.ndarray):
+        """frames: uint8 [n, H, W, 4] host array."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, h, w, c = frames.shape
+        assert c == 4 and (w, h) == (self.width, self.height), "call set_geometry(w, h, max_batch) first"
+        self._check(self._lib.ht_upload_frames(self._h, frames.ctypes.data, n, w * h * 4))
+        self.nframes = n
+
+    def bind_device(self, dev_ptr: int, n: int, frame_stride: int | None = None):
+        """Use n RGBA frames already resident in device memory (e.g. a torch cuda tensor's data_ptr())."""
+        self._check(self._lib.ht_bind_frames_device(self._h, dev_ptr, n, frame_stride or self.width * self.height * 4))
+        self.nframes = n
+
+    # -- detect -----------------------------------------------------------------------------------------------
+    def detect_enqueue(self, flags: int = HT_INPUT_RGBA):
+        self._check(self._lib.ht_detect_enqueue(self._h, flags))
+
+    def detect_collect(self, cap: int = 1 << 16):
+        hits = np.zeros(cap, dtype=HIT_DTYPE)
+        counts = np.zeros(max(1, self.nframes), dtype=np.uint32)
+        total = C.c_uint32(0)
+        self._check(self._lib.ht_detect_collect(self._h, hits.ctypes.data, cap, counts.ctypes.data, C.byref(total)))
+        return hits[: total.value].copy(), counts[: self.nframes]
+
+    def detect_raw(self, frames: np.ndarray, flags: int = HT_INPUT_RGBA, cap: int = 1 << 16):
+        """ccv.grayscale + ccv.detect_objects(..., min_neighbors = 0) for a batch: (hits, per-frame counts)."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        if frames.ndim == 3:
+            frames = frames[None]
+        n, h, w, _ = frames.shape
+        if (w, h) != (self.width, self.height) or n > getattr(self, "_max_batch", 0):
+            self.set_geometry(w, h, n)
+            self._max_batch = n
+        self.upload(frames)
+        self.detect_enqueue(flags)
+        return self.detect_collect(cap)
+
+    def hits_to_rects(self, hits: np.ndarray) -> np.ndarray:
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        out = np.zeros(len(hits), dtype=RECT_DTYPE)
+        if len(hits):
+            self._check(self._lib.ht_hits_to_rects(self._h, hits.ctypes.data, len(hits), out.ctypes.data))
+        return out
+
+    def group_rects(self, rects: np.ndarray, min_neighbors: int = 1) -> np.ndarray:
+        rects = np.ascontiguousarray(rects, dtype=RECT_DTYPE)
+        out = np.zeros(max(1, len(rects)), dtype=RECT_DTYPE)
+        n = C.c_uint32(0)
+        self._check(self._lib.ht_group_rects(rects.ctypes.data, len(rects), min_neighbors, out.ctypes.data, C.byref(n)))
+        return out[: n.value].copy()
+
+    def detect_objects(self, frames: np.ndarray, min_neighbors: int = 1, flags: int = HT_INPUT_RGBA):
+        """Per frame: the list ccv.detect_objects(canvas, cascade, interval, min_neighbors) returns (ccv.js:109-333)."""
+        hits, counts = self.detect_raw(frames, flags)
+        out, k = [], 0
+        for c in counts:
+            r = self.hits_to_rects(hits[k : k + int(c)])
+            out.append(self.group_rects(r, min_neighbors) if min_neighbors > 0 else r)
+            k += int(c)
+        return out
+
+    def pyramid_readback(self, frame: int, level: int, slot: int = 0) -> np.ndarray:
+        p = self.plane(level, slot)
+        out = np.zeros((p.height, p.width), dtype=np.uint8)
+        self._check(self._lib.ht_pyramid_readback(self._h, frame, level, slot, out.ctypes.data, out.size))
+        return out
+
+    def stage_counts(self) -> np.ndarray:
+        n = self.cascade.count + 1
+        out = np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.ht_stage_counts(self._h, out.ctypes.data, n))
+        return out
+
+    def grayscale(self, frames: np.ndarray) -> np.ndarray:
+        """ccv.grayscale for a batch of host RGBA frames; returns the gray RGBA copy."""
+        out = np.ascontiguousarray(frames, dtype=np.uint8).copy()
+        if out.ndim == 3:
+            out = out[None]
+        n, h, w, _ = out.shape
+        self._check(self._lib.ht_grayscale_batch(self._h, out.ctypes.data, n, w, h, w * h * 4))
+        return out
+
+    def whitebalance(self) -> np.ndarray:
+        """headtrackr.getWhitebalance for every bound frame."""
+        out = np.zeros(self.nframes, dtype=np.float64)
+        self._check(self._lib.ht_whitebalance_batch(self._h, out.ctypes.data, self.nframes))
+        return out
+
+    # -- camshift -----------------------------------------------------------------------------------------------
+    def camshift_reserve(self, nstreams: int):
+        self._check(self._lib.ht_camshift_reserve(self._h, nstreams))
+
+    def camshift_init(self, rects, first: int = 0):
+        r = np.zeros(len(rects), dtype=native.CS_RECT_DTYPE)
+        for i, (x, y, w, h) in enumerate(rects):
+            r[i] = (x, y, w, h)
+        self._check(self._lib.ht_camshift_init_batch(self._h, first, len(rects), r.ctypes.data))
+
+    def camshift_track(self, n: int, calc_angles: bool = True, first: int = 0, fetch: bool = True):
+        out = np.zeros(n, dtype=native.CS_TRACKOBJ_DTYPE)
+        self._check(self._lib.ht_camshift_track_batch(self._h, first, n, int(calc_angles), out.ctypes.data if fetch else None))
+        return out
+
+    # -- measurement --------------------------------------------------------------------------------------------
+    def profile(self, on: bool = True):
+        self._check(self._lib.ht_profile(self._h, int(on)))
+
+    def kernel_times(self, reset: bool = True) -> dict:
+        buf = np.zeros(32, dtype=native.KERNEL_TIME_DTYPE)
+        n = C.c_int32(32)
+        self._check(self._lib.ht_kernel_times(self._h, buf.ctypes.data, C.byref(n), int(reset)))
+        return {b["name"].decode(): dict(ms=float(b["ms"]), launches=int(b["launches"])) for b in buf[: n.value]}
+
+    def synchronize(self):
+        self._check(self._lib.ht_synchronize(self._h))
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.ht_stream(self._h) or 0)

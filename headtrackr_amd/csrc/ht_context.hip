@@ -1,0 +1,761 @@
+// ht_context.hip — context lifetime, cascade tables, pyramid geometry, frame binding, result collection and the
+// host-side post-processing (rect conversion + grouping) of libheadtrackr_hip.so.
+//
+// Reference behaviour restated here (paths under /root/reference/src/):
+//   geometry            ccv.js:110-147      (scale, scale_upto, level sizes, variant planes)
+//   hits -> seq rects   ccv.js:227-234,244-245
+//   grouping            ccv.js:34-107 (array_group), 249-332 (averaging, nested-rect filter)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "ht_internal.h"
+
+static thread_local std::string g_create_err;
+
+ht_status ht_fail(ht_ctx *ctx, ht_status st, const std::string &msg) {
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_create_err = msg;
+    return st;
+}
+
+HtProfScope::HtProfScope(ht_ctx *c, const char *name) : ctx(c) {
+    if (!ctx->profiling) return;
+    for (size_t i = 0; i < ctx->timers.size(); i++)
+        if (ctx->timers[i].name == name) idx = (int)i;
+    if (idx < 0) {
+        ctx->timers.emplace_back();
+        ctx->timers.back().name = name;
+        idx = (int)ctx->timers.size() - 1;
+    }
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+        idx = -1;
+        return;
+    }
+    (void)hipEventRecord(a, ctx->stream);
+}
+HtProfScope::~HtProfScope() {
+    if (idx < 0) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->timers[idx].pending.emplace_back(a, b);
+    ctx->timers[idx].launches++;
+}
+
+extern "C" int32_t ht_abi_version(void) { return HT_ABI_VERSION; }
+
+extern "C" const char *ht_last_error(const ht_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------------------
+// cascade
+
+static bool parse_blob(const uint8_t *blob, size_t len, ht_ctx *c, std::string &why) {
+    if (!blob || len < 32 || std::memcmp(blob, "HTCB", 4) != 0) {
+        why = "cascade blob: bad magic";
+        return false;
+    }
+    uint32_t h[8];
+    std::memcpy(h, blob, 32);
+    if (h[1] != 1 || h[6] != HT_MAXPTS) {
+        why = "cascade blob: unsupported version";
+        return false;
+    }
+    c->nstages = h[2];
+    c->cw = h[3];
+    c->ch = h[4];
+    c->nfeat = h[5];
+    if (c->nstages == 0 || c->nstages > 63 || c->cw < 4 || c->ch < 4 || c->cw > 64 || c->ch > 64) {
+        why = "cascade blob: unsupported stage count or window size";
+        return false;
+    }
+    if (len != 32 + (size_t)c->nstages * sizeof(HtBlobStage) + (size_t)c->nfeat * sizeof(HtBlobFeature)) {
+        why = "cascade blob: truncated";
+        return false;
+    }
+    c->h_stages.resize(c->nstages);
+    c->h_feats.resize(c->nfeat);
+    std::memcpy(c->h_stages.data(), blob + 32, c->nstages * sizeof(HtBlobStage));
+    std::memcpy(c->h_feats.data(), blob + 32 + c->nstages * sizeof(HtBlobStage), c->nfeat * sizeof(HtBlobFeature));
+    uint32_t first = 0;
+    for (uint32_t j = 0; j < c->nstages; j++) {
+        if (c->h_stages[j].first != first || first + c->h_stages[j].count > c->nfeat) {
+            why = "cascade blob: inconsistent stage table";
+            return false;
+        }
+        first += c->h_stages[j].count;
+    }
+    for (uint32_t k = 0; k < c->nfeat; k++) {
+        const HtBlobFeature &f = c->h_feats[k];
+        // the reference reads slot 0 of both polarities unconditionally (ccv.js:191-192)
+        if (f.size == 0 || f.size > HT_MAXPTS || f.pz[0] < 0 || f.nz[0] < 0) {
+            why = "cascade blob: feature without a valid first point";
+            return false;
+        }
+        for (int q = 0; q < f.size; q++) {
+            const int lim[3] = {(int)c->cw, (int)c->cw / 2, (int)c->cw / 4};
+            const int limy[3] = {(int)c->ch, (int)c->ch / 2, (int)c->ch / 4};
+            if (f.pz[q] > 2 || f.nz[q] > 2 ||
+                (f.pz[q] >= 0 && (f.px[q] < 0 || f.py[q] < 0 || f.px[q] >= lim[f.pz[q]] || f.py[q] >= limy[f.pz[q]])) ||
+                (f.nz[q] >= 0 && (f.nx[q] < 0 || f.ny[q] < 0 || f.nx[q] >= lim[f.nz[q]] || f.ny[q] >= limy[f.nz[q]]))) {
+                why = "cascade blob: feature point outside the window";
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// alpha * 1e8 is an exact integer iff the decimal literal had <= 8 fractional digits: then (double)k / 1e8 == alpha
+static bool as_decimal8(double v, int64_t *out) {
+    double s = v * 1e8;
+    if (!(std::fabs(s) < 9.0e15)) return false;
+    int64_t k = (int64_t)std::llround(s);
+    if ((double)k / 1e8 != v) return false;
+    *out = k;
+    return true;
+}
+
+static ht_status upload_cascade(ht_ctx *c) {
+    std::vector<HtDeepFeature> deep(c->nfeat);
+    std::vector<HtDevStage> st(c->nstages);
+    c->decimal_alphas = true;
+    for (uint32_t k = 0; k < c->nfeat; k++) {
+        const HtBlobFeature &f = c->h_feats[k];
+        HtDeepFeature &d = deep[k];
+        int np = 0, nn = 0;
+        for (int q = 0; q < f.size; q++) {
+            if (f.pz[q] >= 0) {
+                d.px[np] = f.px[q];
+                d.py[np] = f.py[q];
+                d.pz[np] = f.pz[q];
+                np++;
+            }
+            if (f.nz[q] >= 0) {
+                d.nx[nn] = f.nx[q];
+                d.ny[nn] = f.ny[q];
+                d.nz[nn] = f.nz[q];
+                nn++;
+            }
+        }
+        for (int q = np; q < HT_MAXPTS; q++) d.px[q] = d.px[0], d.py[q] = d.py[0], d.pz[q] = d.pz[0];
+        for (int q = nn; q < HT_MAXPTS; q++) d.nx[q] = d.nx[0], d.ny[q] = d.ny[0], d.nz[q] = d.nz[0];
+        d.a0 = f.alpha[0];
+        d.a1 = f.alpha[1];
+        d.a0i = d.a1i = 0;
+        if (!as_decimal8(d.a0, &d.a0i) || !as_decimal8(d.a1, &d.a1i)) c->decimal_alphas = false;
+    }
+    for (uint32_t j = 0; j < c->nstages; j++) {
+        st[j].first = c->h_stages[j].first;
+        st[j].count = c->h_stages[j].count;
+        st[j].threshold = c->h_stages[j].threshold;
+        st[j].thri = 0;
+        st[j].pad = 0;
+        if (!as_decimal8(st[j].threshold, &st[j].thri)) c->decimal_alphas = false;
+        uint32_t mp = 1;
+        for (uint32_t k = 0; k < st[j].count; k++) {
+            const HtBlobFeature &f = c->h_feats[st[j].first + k];
+            uint32_t np = 0, nn = 0;
+            for (int q = 0; q < f.size; q++) np += f.pz[q] >= 0, nn += f.nz[q] >= 0;
+            mp = std::max(mp, std::max(np, nn));
+        }
+        st[j].maxpts = mp;
+    }
+    HT_HIP(c, hipMalloc(&c->d_deep_feats, deep.size() * sizeof(HtDeepFeature)));
+    HT_HIP(c, hipMalloc(&c->d_stages, st.size() * sizeof(HtDevStage)));
+    HT_HIP(c, hipMemcpy(c->d_deep_feats, deep.data(), deep.size() * sizeof(HtDeepFeature), hipMemcpyHostToDevice));
+    HT_HIP(c, hipMemcpy(c->d_stages, st.data(), st.size() * sizeof(HtDevStage), hipMemcpyHostToDevice));
+    return ht_scan_tile_tables(c);
+}
+
+extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, size_t cascade_len, ht_ctx **out) {
+    if (!cfg || !out || cfg->struct_size != sizeof(ht_config)) return ht_fail(nullptr, HT_ERR_INVALID, "ht_create: bad config");
+    *out = nullptr;
+    if (cfg->interval < 1 || cfg->interval > 12) return ht_fail(nullptr, HT_ERR_INVALID, "ht_create: interval must be 1..12");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return ht_fail(nullptr, HT_ERR_NO_DEVICE, "ht_create: no HIP device visible (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return ht_fail(nullptr, HT_ERR_INVALID, "ht_create: device ordinal out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device) != hipSuccess) return ht_fail(nullptr, HT_ERR_HIP, "hipGetDeviceProperties failed");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return ht_fail(nullptr, HT_ERR_NO_DEVICE, std::string("ht_create: device is ") + prop.gcnArchName + ", this build is gfx950-only");
+    ht_ctx *c = new (std::nothrow) ht_ctx();
+    if (!c) return ht_fail(nullptr, HT_ERR_NOMEM, "ht_create: out of host memory");
+    c->device = cfg->device;
+    c->interval = cfg->interval;
+    c->next = cfg->interval + 1;
+    if (cfg->hit_capacity) c->hit_capacity = cfg->hit_capacity;
+    c->queue_capacity_cfg = cfg->queue_capacity;
+    std::string why;
+    if (!parse_blob((const uint8_t *)cascade_blob, cascade_len, c, why)) {
+        delete c;
+        return ht_fail(nullptr, HT_ERR_INVALID, "ht_create: " + why);
+    }
+    ht_status st = HT_OK;
+    auto bail = [&](ht_status s) {
+        g_create_err = c->err;
+        ht_destroy(c);
+        return s;
+    };
+    if (hipSetDevice(c->device) != hipSuccess) {
+        c->err = "hipSetDevice failed";
+        return bail(HT_ERR_HIP);
+    }
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            c->err = "hipStreamCreate failed";
+            return bail(HT_ERR_HIP);
+        }
+        c->own_stream = true;
+    }
+    c->split_stage = std::min<uint32_t>(4, c->nstages);
+    if ((st = upload_cascade(c)) != HT_OK) return bail(st);
+    if (hipMalloc(&c->d_counters, sizeof(HtCounters)) != hipSuccess ||
+        hipMalloc(&c->d_hits, (size_t)c->hit_capacity * sizeof(ht_hit)) != hipSuccess) {
+        c->err = "hipMalloc(hits) failed";
+        return bail(HT_ERR_NOMEM);
+    }
+    *out = c;
+    return HT_OK;
+}
+
+static void free_geometry(ht_ctx *c) {
+    if (c->d_levels) (void)hipFree(c->d_levels), c->d_levels = nullptr;
+    if (c->d_arena) (void)hipFree(c->d_arena), c->d_arena = nullptr;
+    if (c->d_scales) (void)hipFree(c->d_scales), c->d_scales = nullptr;
+    if (c->d_queue) (void)hipFree(c->d_queue), c->d_queue = nullptr;
+    for (auto p : c->d_gens)
+        if (p) (void)hipFree(p);
+    c->d_gens.clear();
+    c->h_gens.clear();
+    c->gen_blocks.clear();
+    c->h_scales.clear();
+}
+
+extern "C" void ht_destroy(ht_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_geometry(c);
+    if (c->d_tile_feats) (void)hipFree(c->d_tile_feats);
+    if (c->d_deep_feats) (void)hipFree(c->d_deep_feats);
+    if (c->d_stages) (void)hipFree(c->d_stages);
+    if (c->d_frames_own) (void)hipFree(c->d_frames_own);
+    if (c->d_hits) (void)hipFree(c->d_hits);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_cs) (void)hipFree(c->d_cs);
+    if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
+    if (c->d_cs_out) (void)hipFree(c->d_cs_out);
+    for (auto &t : c->timers)
+        for (auto &p : t.pending) (void)hipEventDestroy(p.first), (void)hipEventDestroy(p.second);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// geometry, ccv.js:110-147
+
+// V8's Math.pow(Math.pow(2, 1/6), i) for i = 0..5: glibc's pow() is one ulp off for i = 4, and Math.floor(W / pow)
+// (ccv.js:119-120) must see the same divisor the JavaScript reference saw.
+static const uint64_t kV8Scale6Pow[6] = {0x3ff0000000000000ULL, 0x3ff1f59ac3c7d6c0ULL, 0x3ff428a2f98d728bULL,
+                                         0x3ff6a09e667f3bcdULL, 0x3ff965fea53d6e3eULL, 0x3ffc823e074ec12bULL};
+static double bits2d(uint64_t u) {
+    double d;
+    std::memcpy(&d, &u, 8);
+    return d;
+}
+static double ht_scale_of(int interval) { return interval == 5 ? bits2d(kV8Scale6Pow[1]) : std::pow(2.0, 1.0 / (interval + 1)); }
+static double ht_scale_pow(int interval, int i) {
+    return (interval == 5 && i >= 0 && i <= 5) ? bits2d(kV8Scale6Pow[i]) : std::pow(ht_scale_of(interval), (double)i);
+}
+
+static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, int32_t max_batch, const int32_t *level_dims,
+                                     int32_t nlevels_in) {
+    if (!c) return HT_ERR_INVALID;
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384 || max_batch <= 0)
+        return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: width/height must be 1..16384 and max_batch > 0");
+    HT_HIP(c, hipSetDevice(c->device));
+    const int next = c->next;
+    const int upto = (int)std::floor(std::log((double)std::min(c->cw, c->ch)) / std::log(ht_scale_of(c->interval)));  // ccv.js:112
+    const int n = upto + next * 2;  // ccv.js:113
+    if (n > HT_MAX_LEVELS) return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: too many pyramid levels");
+    if (level_dims && nlevels_in != n) return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: level_dims has the wrong number of levels");
+    if (c->W == width && c->H == height && c->max_batch >= max_batch && c->nlevels == n && !level_dims) return HT_OK;
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    free_geometry(c);
+    c->W = width;
+    c->H = height;
+    c->max_batch = max_batch;
+    c->nlevels = n;
+    c->upto = upto;
+
+    uint64_t off = 0;
+    c->pyr_bytes = 0;
+    for (int i = 0; i < n; i++) {
+        HtDevLevel &L = c->h_levels[i];
+        if (level_dims) {
+            L.w = level_dims[2 * i];
+            L.h = level_dims[2 * i + 1];
+            if (L.w < 0 || L.h < 0 || L.w > width || L.h > height || (i == 0 && (L.w != width || L.h != height)))
+                return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: bad level_dims");
+        } else if (i == 0) {
+            L.w = width;
+            L.h = height;
+        } else if (i <= c->interval) {  // ccv.js:119-120
+            L.w = (int)std::floor((double)width / ht_scale_pow(c->interval, i));
+            L.h = (int)std::floor((double)height / ht_scale_pow(c->interval, i));
+        } else {  // ccv.js:126-127
+            L.w = c->h_levels[i - next].w / 2;
+            L.h = c->h_levels[i - next].h / 2;
+        }
+        L.stride = (int)align_up((uint64_t)L.w, 4);
+        for (int s = 0; s < 4; s++) {
+            if (s == 0 || i >= 2 * next) {  // ccv.js:131
+                if (off > 0xfffffff0ull) return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: frame too large");
+                L.off[s] = (uint32_t)off;
+                off = align_up(off + (uint64_t)L.stride * L.h, 256);
+                c->pyr_bytes += (uint64_t)L.w * L.h;
+            } else {
+                L.off[s] = 0xffffffffu;
+            }
+        }
+    }
+    c->arena_stride = align_up(off + 256, 256);
+
+    // resample jobs by dependency generation (generation 0 = the gray plane itself)
+    std::vector<int> gen(n, 0);
+    int ngen = 1;
+    for (int i = 1; i < n; i++) {
+        gen[i] = (i <= c->interval) ? 1 : gen[i - next] + 1;
+        ngen = std::max(ngen, gen[i] + 1);
+    }
+    c->h_gens.assign(ngen, {});
+    auto add_job = [&](int g, int src, int dst, int slot, int sx, int sy, int sw, int sh, int dw, int dh) {
+        const HtDevLevel &S = c->h_levels[src], &D = c->h_levels[dst];
+        if (D.w <= 0 || D.h <= 0) return;
+        HtResampleJob j;
+        std::memset(&j, 0, sizeof(j));
+        j.src_off = S.off[0];
+        j.dst_off = D.off[slot];
+        j.src_stride = S.stride;
+        j.dst_stride = D.stride;
+        j.sx = sx, j.sy = sy, j.sw = sw, j.sh = sh;
+        j.dw = dw, j.dh = dh;
+        j.cw = D.w, j.ch = D.h;
+        if (sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) {  // nothing is drawn: the canvas stays transparent black
+            j.dw = j.dh = 0;
+            j.sw = j.sh = 1;
+            j.rx = j.ry = 1;
+        } else {
+            j.rx = (double)sw / (double)dw;
+            j.ry = (double)sh / (double)dh;
+        }
+        c->h_gens[g].push_back(j);
+    };
+    for (int i = 1; i < n; i++) {
+        const HtDevLevel &D = c->h_levels[i];
+        if (i <= c->interval) {  // ccv.js:121
+            add_job(gen[i], 0, i, 0, 0, 0, c->h_levels[0].w, c->h_levels[0].h, D.w, D.h);
+        } else {  // ccv.js:128
+            const HtDevLevel &S = c->h_levels[i - next];
+            add_job(gen[i], i - next, i, 0, 0, 0, S.w, S.h, D.w, D.h);
+            if (i >= 2 * next) {  // ccv.js:135,140,145
+                add_job(gen[i], i - next, i, 1, 1, 0, S.w - 1, S.h, D.w - 2, D.h);
+                add_job(gen[i], i - next, i, 2, 0, 1, S.w, S.h - 1, D.w, D.h - 2);
+                add_job(gen[i], i - next, i, 3, 1, 1, S.w - 1, S.h - 1, D.w - 2, D.h - 2);
+            }
+        }
+    }
+    c->d_gens.assign(ngen, nullptr);
+    c->gen_blocks.assign(ngen, 0);
+    for (int g = 1; g < ngen; g++) {
+        uint32_t b = 0;
+        for (auto &j : c->h_gens[g]) {
+            j.block_begin = b;
+            j.blocks_x = (uint32_t)((j.cw + 127) / 128);
+            b += j.blocks_x * (uint32_t)((j.ch + 7) / 8);
+        }
+        c->gen_blocks[g] = b;
+        if (c->h_gens[g].empty()) continue;
+        HT_HIP(c, hipMalloc(&c->d_gens[g], c->h_gens[g].size() * sizeof(HtResampleJob)));
+        HT_HIP(c, hipMemcpy(c->d_gens[g], c->h_gens[g].data(), c->h_gens[g].size() * sizeof(HtResampleJob), hipMemcpyHostToDevice));
+    }
+
+    HT_HIP(c, hipMalloc(&c->d_levels, sizeof(HtDevLevel) * HT_MAX_LEVELS));
+    HT_HIP(c, hipMemcpy(c->d_levels, c->h_levels, sizeof(HtDevLevel) * n, hipMemcpyHostToDevice));
+    if (hipMalloc(&c->d_arena, c->arena_stride * (uint64_t)max_batch) != hipSuccess)
+        return ht_fail(c, HT_ERR_NOMEM, "ht_set_geometry: hipMalloc(pyramid arena) failed");
+    HT_HIP(c, hipMemset(c->d_arena, 0, c->arena_stride * (uint64_t)max_batch));
+
+    ht_status st = ht_scan_plan_tiles(c);
+    if (st != HT_OK) return st;
+
+    // survivor queue between the tile kernel and the deep kernel: 1/8 of all windows unless configured
+    uint64_t qc = c->queue_capacity_cfg ? c->queue_capacity_cfg : std::max<uint64_t>(1u << 16, c->windows_per_frame * (uint64_t)max_batch / 8);
+    qc = std::min<uint64_t>(qc, 1ull << 28);
+    c->queue_capacity = (uint32_t)qc;
+    if (hipMalloc(&c->d_queue, (size_t)qc * sizeof(HtQueueEntry)) != hipSuccess)
+        return ht_fail(c, HT_ERR_NOMEM, "ht_set_geometry: hipMalloc(survivor queue) failed");
+    c->nframes = 0;
+    c->d_frames = nullptr;
+    c->enqueued = false;
+    return HT_OK;
+}
+
+extern "C" int32_t ht_num_levels(const ht_ctx *c) { return c ? c->nlevels : 0; }
+extern "C" uint64_t ht_windows_per_frame(const ht_ctx *c) { return c ? c->windows_per_frame : 0; }
+extern "C" uint64_t ht_pyramid_bytes_per_frame(const ht_ctx *c) { return c ? c->pyr_bytes : 0; }
+
+extern "C" ht_status ht_plane(const ht_ctx *c, int32_t level, int32_t slot, ht_plane_info *out) {
+    if (!c || !out || level < 0 || level >= c->nlevels || slot < 0 || slot > 3) return HT_ERR_INVALID;
+    const HtDevLevel &L = c->h_levels[level];
+    out->width = L.w;
+    out->height = L.h;
+    out->stride = L.stride;
+    out->present = L.off[slot] != 0xffffffffu;
+    out->offset = out->present ? L.off[slot] : 0;
+    return HT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// frames
+
+extern "C" ht_status ht_upload_frames(ht_ctx *c, const uint8_t *host_rgba, int32_t n, size_t frame_stride) {
+    if (!c) return HT_ERR_INVALID;
+    if (c->W == 0) return ht_fail(c, HT_ERR_STATE, "ht_upload_frames: call ht_set_geometry first");
+    const size_t fbytes = (size_t)c->W * c->H * 4;
+    if (!host_rgba || n <= 0 || n > c->max_batch || frame_stride < fbytes)
+        return ht_fail(c, HT_ERR_INVALID, "ht_upload_frames: bad frame count or stride");
+    HT_HIP(c, hipSetDevice(c->device));
+    const size_t need = fbytes * (size_t)n;
+    if (c->d_frames_own_bytes < need) {
+        HT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_frames_own) (void)hipFree(c->d_frames_own);
+        c->d_frames_own = nullptr;
+        c->d_frames_own_bytes = 0;
+        if (hipMalloc(&c->d_frames_own, need) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "ht_upload_frames: hipMalloc failed");
+        c->d_frames_own_bytes = need;
+    }
+    if (frame_stride == fbytes) {
+        HT_HIP(c, hipMemcpyAsync(c->d_frames_own, host_rgba, need, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HT_HIP(c, hipMemcpy2DAsync(c->d_frames_own, fbytes, host_rgba, frame_stride, fbytes, (size_t)n, hipMemcpyHostToDevice, c->stream));
+    }
+    c->d_frames = c->d_frames_own;
+    c->frame_stride = fbytes;
+    c->nframes = n;
+    return HT_OK;
+}
+
+extern "C" ht_status ht_bind_frames_device(ht_ctx *c, const void *dev_rgba, int32_t n, size_t frame_stride) {
+    if (!c) return HT_ERR_INVALID;
+    if (c->W == 0) return ht_fail(c, HT_ERR_STATE, "ht_bind_frames_device: call ht_set_geometry first");
+    if (!dev_rgba || n <= 0 || n > c->max_batch || frame_stride < (size_t)c->W * c->H * 4 || (frame_stride & 3) ||
+        ((uintptr_t)dev_rgba & 3))
+        return ht_fail(c, HT_ERR_INVALID, "ht_bind_frames_device: bad pointer, frame count or stride (4-byte alignment required)");
+    c->d_frames = (const uint8_t *)dev_rgba;
+    c->frame_stride = frame_stride;
+    c->nframes = n;
+    return HT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// detect
+
+extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
+    if (!c) return HT_ERR_INVALID;
+    if (!c->d_frames || c->nframes <= 0) return ht_fail(c, HT_ERR_STATE, "ht_detect_enqueue: no frames bound");
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(HtCounters), c->stream));
+    ht_status st = ht_launch_pyramid(c, flags);
+    if (st != HT_OK) return st;
+    st = ht_launch_scan(c, flags);
+    if (st != HT_OK) return st;
+    c->enqueued = true;
+    return HT_OK;
+}
+
+static inline bool hit_less(const ht_hit &a, const ht_hit &b) {  // emission order, ccv.js:154,178,181-182
+    if (a.frame != b.frame) return a.frame < b.frame;
+    if (a.scale != b.scale) return a.scale < b.scale;
+    if (a.q != b.q) return a.q < b.q;
+    if (a.y != b.y) return a.y < b.y;
+    return a.x < b.x;
+}
+
+extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, uint32_t *counts, uint32_t *total) {
+    if (!c) return HT_ERR_INVALID;
+    if (!c->enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_collect: nothing enqueued");
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipMemcpyAsync(&c->h_counters, c->d_counters, sizeof(HtCounters), hipMemcpyDeviceToHost, c->stream));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    c->enqueued = false;
+    const uint32_t found = c->h_counters.nhits;
+    if (total) *total = found;
+    if (counts) std::memset(counts, 0, sizeof(uint32_t) * (size_t)c->nframes);
+    if (found > c->hit_capacity)
+        return ht_fail(c, HT_ERR_CAPACITY, "ht_detect_collect: more raw hits than ht_config.hit_capacity; results incomplete");
+    std::vector<ht_hit> tmp(found);
+    if (found) {
+        HT_HIP(c, hipMemcpy(tmp.data(), c->d_hits, (size_t)found * sizeof(ht_hit), hipMemcpyDeviceToHost));
+        std::sort(tmp.begin(), tmp.end(), hit_less);
+    }
+    if (counts)
+        for (uint32_t i = 0; i < found; i++)
+            if (tmp[i].frame < (uint32_t)c->nframes) counts[tmp[i].frame]++;
+    const uint32_t ncopy = std::min(found, cap);
+    if (hits && ncopy) std::memcpy(hits, tmp.data(), (size_t)ncopy * sizeof(ht_hit));
+    if (found > cap) return ht_fail(c, HT_ERR_CAPACITY, "ht_detect_collect: caller buffer too small for all hits");
+    return HT_OK;
+}
+
+extern "C" ht_status ht_detect_batch(ht_ctx *c, const uint8_t *host_rgba, int32_t n, int32_t width, int32_t height, size_t frame_stride,
+                                     uint32_t flags, ht_hit *hits, uint32_t cap, uint32_t *counts, uint32_t *total) {
+    if (!c) return HT_ERR_INVALID;
+    ht_status st;
+    if (c->W != width || c->H != height || c->max_batch < n)
+        if ((st = ht_set_geometry(c, width, height, n, nullptr, 0)) != HT_OK) return st;
+    if ((st = ht_upload_frames(c, host_rgba, n, frame_stride)) != HT_OK) return st;
+    if ((st = ht_detect_enqueue(c, flags)) != HT_OK) return st;
+    return ht_detect_collect(c, hits, cap, counts, total);
+}
+
+extern "C" ht_status ht_pyramid_readback(ht_ctx *c, int32_t frame, int32_t level, int32_t slot, uint8_t *out, size_t cap) {
+    if (!c || !out) return HT_ERR_INVALID;
+    if (frame < 0 || frame >= c->max_batch || level < 0 || level >= c->nlevels || slot < 0 || slot > 3)
+        return ht_fail(c, HT_ERR_INVALID, "ht_pyramid_readback: index out of range");
+    const HtDevLevel &L = c->h_levels[level];
+    if (L.off[slot] == 0xffffffffu) return ht_fail(c, HT_ERR_INVALID, "ht_pyramid_readback: plane does not exist");
+    if (cap < (size_t)L.w * L.h) return ht_fail(c, HT_ERR_CAPACITY, "ht_pyramid_readback: buffer too small");
+    if (L.w == 0 || L.h == 0) return HT_OK;
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    HT_HIP(c, hipMemcpy2D(out, L.w, c->d_arena + (uint64_t)frame * c->arena_stride + L.off[slot], L.stride, L.w, L.h, hipMemcpyDeviceToHost));
+    return HT_OK;
+}
+
+extern "C" ht_status ht_stage_counts(ht_ctx *c, uint64_t *counts, int32_t n) {
+    if (!c || !counts || n < (int32_t)c->nstages + 1) return HT_ERR_INVALID;
+    for (uint32_t j = 0; j <= c->nstages; j++) counts[j] = c->h_counters.stage_in[j];
+    return HT_OK;
+}
+
+extern "C" ht_status ht_grayscale_batch(ht_ctx *c, uint8_t *host_rgba, int32_t n, int32_t width, int32_t height, size_t frame_stride) {
+    if (!c || !host_rgba || n <= 0 || width <= 0 || height <= 0 || frame_stride < (size_t)width * height * 4) return HT_ERR_INVALID;
+    HT_HIP(c, hipSetDevice(c->device));
+    const size_t fbytes = (size_t)width * height * 4;
+    uint8_t *d = nullptr;
+    if (hipMalloc(&d, fbytes * n) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "ht_grayscale_batch: hipMalloc failed");
+    ht_status st = HT_OK;
+    hipError_t e = hipMemcpy2DAsync(d, fbytes, host_rgba, frame_stride, fbytes, n, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        const int W0 = c->W, H0 = c->H;
+        c->W = width, c->H = height;  // the in-place kernel only needs the pixel count
+        st = ht_launch_gray_inplace(c, d, n, fbytes);
+        c->W = W0, c->H = H0;
+    }
+    if (e == hipSuccess && st == HT_OK) e = hipMemcpy2DAsync(host_rgba, frame_stride, d, fbytes, fbytes, n, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return ht_fail(c, HT_ERR_HIP, std::string("ht_grayscale_batch: ") + hipGetErrorString(e));
+    return st;
+}
+
+extern "C" ht_status ht_whitebalance_batch(ht_ctx *c, double *out, int32_t n) {
+    if (!c || !out) return HT_ERR_INVALID;
+    if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_whitebalance_batch: no frames bound");
+    HT_HIP(c, hipSetDevice(c->device));
+    const size_t need = sizeof(unsigned long long) * 4 * (size_t)c->max_batch;
+    if (c->d_scratch_bytes < need) {
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        HT_HIP(c, hipMalloc(&c->d_scratch, need));
+        c->d_scratch_bytes = need;
+    }
+    ht_status st = ht_launch_whitebalance(c, c->d_scratch);
+    if (st != HT_OK) return st;
+    std::vector<unsigned long long> sums((size_t)n * 4);
+    HT_HIP(c, hipMemcpyAsync(sums.data(), c->d_scratch, sizeof(unsigned long long) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    const double imagesize = (double)c->W * (double)c->H;  // whitebalance.js:14
+    for (int i = 0; i < n; i++) {
+        // r, g, b are sums of integers < 2^53: exactly what the reference's double accumulation holds (whitebalance.js:17-21)
+        const double avgr = (double)sums[4 * i] / imagesize, avgg = (double)sums[4 * i + 1] / imagesize, avgb = (double)sums[4 * i + 2] / imagesize;
+        out[i] = (avgr + avgg + avgb) / 3;  // whitebalance.js:23-26
+    }
+    return HT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host post-processing
+
+extern "C" ht_status ht_hits_to_rects(const ht_ctx *c, const ht_hit *hits, uint32_t n, ht_rect *out) {
+    if (!c || (n && (!hits || !out))) return HT_ERR_INVALID;
+    double sx[HT_MAX_LEVELS];
+    const double scale = ht_scale_of(c->interval);  // ccv.js:110
+    sx[0] = 1;                                      // ccv.js:150
+    for (int i = 1; i < HT_MAX_LEVELS; i++) sx[i] = sx[i - 1] * scale;  // ccv.js:244-245 (repeated multiplication)
+    for (uint32_t k = 0; k < n; k++) {
+        const ht_hit &h = hits[k];
+        if (h.scale >= HT_MAX_LEVELS) return HT_ERR_INVALID;
+        const double s = sx[h.scale];
+        out[k].x = (double)(h.x * 4 + (h.q & 1) * 2) * s;   // ccv.js:228
+        out[k].y = (double)(h.y * 4 + (h.q >> 1) * 2) * s;  // ccv.js:229
+        out[k].width = (double)c->cw * s;                   // ccv.js:230
+        out[k].height = (double)c->ch * s;                  // ccv.js:231
+        out[k].confidence = h.sum;                          // ccv.js:233
+        out[k].neighbors = 1;                               // ccv.js:232
+        out[k].reserved = 0;
+    }
+    return HT_OK;
+}
+
+namespace {
+struct Node {
+    int parent, rank;
+};
+inline bool similar(const ht_rect &r1, const ht_rect &r2) {  // ccv.js:252-261
+    const double distance = std::floor(r1.width * 0.25 + 0.5);
+    return r2.x <= r1.x + distance && r2.x >= r1.x - distance && r2.y <= r1.y + distance && r2.y >= r1.y - distance &&
+           r2.width <= std::floor(r1.width * 1.5 + 0.5) && std::floor(r2.width * 1.5 + 0.5) >= r1.width;
+}
+}  // namespace
+
+extern "C" ht_status ht_group_rects(const ht_rect *seq, uint32_t n, int32_t min_neighbors, ht_rect *out, uint32_t *nout) {
+    if (!nout || (n && (!seq || !out))) return HT_ERR_INVALID;
+    *nout = 0;
+    if (n == 0) return HT_OK;
+    // union-find with rank and path compression, visiting pairs in the reference's order (ccv.js:41-89)
+    std::vector<Node> node(n, Node{-1, 0});
+    auto find_root = [&](int i) {
+        while (node[i].parent != -1) i = node[i].parent;
+        return i;
+    };
+    auto compress = [&](int i, int root) {
+        while (node[i].parent != -1) {
+            const int t = i;
+            i = node[i].parent;
+            node[t].parent = root;
+        }
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        int root = find_root((int)i);
+        for (uint32_t j = 0; j < n; j++) {
+            if (i == j || !similar(seq[i], seq[j])) continue;
+            const int root2 = find_root((int)j);
+            if (root2 == root) continue;
+            if (node[root].rank > node[root2].rank) {
+                node[root2].parent = root;
+            } else {
+                node[root].parent = root2;
+                if (node[root].rank == node[root2].rank) node[root2].rank++;
+                root = root2;
+            }
+            compress((int)j, root);
+            compress((int)i, root);
+        }
+    }
+    // class ids in first-seen order (ccv.js:90-105)
+    std::vector<int> idx(n);
+    int ncomp = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const int r = find_root((int)i);
+        if (node[r].rank >= 0) node[r].rank = ~ncomp++;
+        idx[i] = ~node[r].rank;
+    }
+    std::vector<ht_rect> comps((size_t)ncomp, ht_rect{0, 0, 0, 0, 0, 0, 0});
+    for (uint32_t i = 0; i < n; i++) {  // ccv.js:274-289
+        ht_rect &cp = comps[idx[i]];
+        if (cp.neighbors == 0) cp.confidence = seq[i].confidence;
+        ++cp.neighbors;
+        cp.x += seq[i].x;
+        cp.y += seq[i].y;
+        cp.width += seq[i].width;
+        cp.height += seq[i].height;
+        cp.confidence = std::max(cp.confidence, seq[i].confidence);
+    }
+    std::vector<ht_rect> seq2;
+    for (int i = 0; i < ncomp; i++) {  // ccv.js:293-303
+        const int nn = comps[i].neighbors;
+        if (nn >= min_neighbors) {
+            ht_rect r;
+            r.x = (comps[i].x * 2 + nn) / (2 * nn);
+            r.y = (comps[i].y * 2 + nn) / (2 * nn);
+            r.width = (comps[i].width * 2 + nn) / (2 * nn);
+            r.height = (comps[i].height * 2 + nn) / (2 * nn);
+            r.neighbors = nn;
+            r.reserved = 0;
+            r.confidence = comps[i].confidence;
+            seq2.push_back(r);
+        }
+    }
+    uint32_t k = 0;
+    for (size_t i = 0; i < seq2.size(); i++) {  // ccv.js:307-330
+        const ht_rect &r1 = seq2[i];
+        bool keep = true;
+        for (size_t j = 0; j < seq2.size() && keep; j++) {
+            const ht_rect &r2 = seq2[j];
+            const double distance = std::floor(r2.width * 0.25 + 0.5);
+            if (i != j && r1.x >= r2.x - distance && r1.y >= r2.y - distance && r1.x + r1.width <= r2.x + r2.width + distance &&
+                r1.y + r1.height <= r2.y + r2.height + distance && (r2.neighbors > std::max(3, r1.neighbors) || r1.neighbors < 3))
+                keep = false;
+        }
+        if (keep) out[k++] = r1;
+    }
+    *nout = k;
+    return HT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// measurement
+
+extern "C" ht_status ht_profile(ht_ctx *c, int32_t on) {
+    if (!c) return HT_ERR_INVALID;
+    c->profiling = on != 0;
+    return HT_OK;
+}
+
+extern "C" ht_status ht_kernel_times(ht_ctx *c, ht_kernel_time *out, int32_t *n, int32_t reset) {
+    if (!c || !n) return HT_ERR_INVALID;
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    for (auto &t : c->timers) {
+        for (auto &p : t.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) t.ms += ms;
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+        t.pending.clear();
+    }
+    const int cap = *n;
+    int k = 0;
+    for (auto &t : c->timers) {
+        if (out && k < cap) {
+            std::memset(&out[k], 0, sizeof(ht_kernel_time));
+            std::strncpy(out[k].name, t.name.c_str(), sizeof(out[k].name) - 1);
+            out[k].ms = t.ms;
+            out[k].launches = t.launches;
+        }
+        k++;
+    }
+    *n = k;
+    if (reset) c->timers.clear();
+    return HT_OK;
+}
+
+extern "C" void *ht_stream(const ht_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+extern "C" ht_status ht_synchronize(ht_ctx *c) {
+    if (!c) return HT_ERR_INVALID;
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    return HT_OK;
+}

@@ -1,0 +1,208 @@
+// ht_internal.h — shared host/device definitions of libheadtrackr_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "headtrackr_hip.h"
+
+#define HT_MAXPTS 8
+
+// ---------------------------------------------------------------------------------------------------------
+// Cascade, host view of the "HTCB" blob (headtrackr_amd/js/cascade_pack.js) == headtrackr.cascade (cascade.js:19)
+struct HtBlobFeature {
+    uint8_t size, pad[7];
+    int8_t px[HT_MAXPTS], py[HT_MAXPTS], pz[HT_MAXPTS];
+    int8_t nx[HT_MAXPTS], ny[HT_MAXPTS], nz[HT_MAXPTS];
+    double alpha[2];
+};
+struct HtBlobStage {
+    uint32_t count, first;
+    double threshold;
+};
+static_assert(sizeof(HtBlobFeature) == 72 && sizeof(HtBlobStage) == 16, "HTCB layout");
+
+// ---------------------------------------------------------------------------------------------------------
+// Device-side cascade tables.
+//
+// Tile kernel: every point of every feature as a byte offset into the workgroup's LDS tile, relative to the
+// window base (see ht_scan.hip "unified-base layout"); read with uniform (scalar) loads, one feature at a time.
+struct alignas(64) HtTileFeature {
+    uint32_t po[HT_MAXPTS / 2];  // positive-point offsets, two u16 per word (low half first); valid ones first, count = np
+    uint32_t no[HT_MAXPTS / 2];  // negative-point offsets, count = nn
+    uint32_t a[4];               // alpha[2k] (lo,hi words), alpha[2k+1] (lo,hi)  (ccv.js:194,219)
+    uint32_t np, nn;
+    uint32_t pad[2];
+};
+static_assert(sizeof(HtTileFeature) == 64, "HtTileFeature");
+
+// Deep kernel: coordinate form, one feature per lane.  Slots >= np / nn repeat slot 0 (min/max are idempotent).
+struct alignas(16) HtDeepFeature {
+    uint8_t px[HT_MAXPTS], py[HT_MAXPTS], pz[HT_MAXPTS];  // each array is read as one 64-bit word on the device
+    uint8_t nx[HT_MAXPTS], ny[HT_MAXPTS], nz[HT_MAXPTS];
+    int64_t a0i, a1i;  // alpha * 1e8 as exact integers (valid when the cascade is "decimal", see ht_context.hip)
+    double a0, a1;
+};
+static_assert(sizeof(HtDeepFeature) == 80, "HtDeepFeature");
+
+struct HtDevStage {
+    uint32_t first, count;
+    uint32_t maxpts;  // max(np, nn) over the stage's features
+    uint32_t pad;
+    double threshold;
+    int64_t thri;  // threshold * 1e8
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Pyramid geometry (ccv.js:110-147), device copy.
+struct HtDevLevel {
+    int32_t w, h, stride;
+    uint32_t off[4];  // byte offset of slot 0..3 inside one frame's arena (0xffffffff = absent)
+};
+
+// One resample job = one canvas of the pyramid (ccv.js:121,128,135,140,145).
+struct HtResampleJob {
+    uint32_t src_off, dst_off;
+    int32_t src_stride, dst_stride;
+    int32_t sx, sy, sw, sh;  // source rect
+    int32_t dw, dh;          // destination rect (at 0,0)
+    int32_t cw, ch;          // destination canvas size (pixels outside dw x dh are written 0)
+    uint32_t block_begin;    // first block of this job inside its generation's grid
+    uint32_t blocks_x;       // blocks per row of the canvas
+    double rx, ry;           // sw/dw, sh/dh computed on the host (binary64 division)
+};
+
+// One scan scale (ccv.js:154-160) and its tiling.
+struct HtScanScale {
+    int32_t l0, l1, l2;   // levels i, i+next, i+2*next
+    int32_t qw, qh;       // windows per row / column on the quarter-resolution plane (ccv.js:155-156)
+    int32_t tw2, th2;     // tile size in half-window steps X', Y' (X' = 2x+dx, Y' = 2y+dy)
+    int32_t ntx, nty;     // tiles per row / column
+    uint32_t tile_begin;  // first tile of this scale in the per-frame tile list
+    uint32_t div_magic;   // ceil(2^20 / tw2): id / tw2 == (id * magic) >> 20 for id < 4096
+    uint32_t win_begin;   // first window of this scale in the flat per-frame window index (simple kernel)
+};
+
+// Survivor handed from the tile kernel to the deep kernel.
+struct HtQueueEntry {
+    uint32_t frame;
+    uint16_t x, y;
+    uint8_t scale, q;
+    uint16_t pad;
+    uint32_t pad2;
+};
+static_assert(sizeof(HtQueueEntry) == 16, "HtQueueEntry");
+
+// Device counters block (zeroed before each batch).
+struct HtCounters {
+    uint32_t nhits;        // hits appended (may exceed capacity)
+    uint32_t nqueue;       // survivors appended to the deep queue (may exceed capacity)
+    uint32_t queue_inline; // survivors that did not fit the queue and were finished inside the tile kernel
+    uint32_t pad;
+    unsigned long long stage_in[64];  // windows that entered stage j; [nstages] = full survivors
+};
+
+// camshift per-stream device state (camshift.js:153-160)
+struct HtCsState {
+    uint32_t model[4096];  // _modelHist
+    int32_t sw[4];         // _searchWindow
+    double x, y, width, height, angle;  // _trackObj
+};
+
+// ---------------------------------------------------------------------------------------------------------
+struct HtKernelTimer {
+    std::string name;
+    double ms = 0;
+    uint32_t launches = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct ht_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // cascade
+    int interval = 5, next = 6;
+    uint32_t cw = 24, ch = 24, nstages = 0, nfeat = 0;
+    bool decimal_alphas = false;  // all alphas / thresholds are k * 1e-8 exactly -> integer decisions allowed
+    std::vector<HtBlobStage> h_stages;
+    std::vector<HtBlobFeature> h_feats;
+    HtTileFeature *d_tile_feats = nullptr;
+    HtDeepFeature *d_deep_feats = nullptr;
+    HtDevStage *d_stages = nullptr;
+    uint32_t split_stage = 4;  // stages [0, split) in the tile kernel, [split, nstages) in the deep kernel
+
+    // geometry
+    int W = 0, H = 0, max_batch = 0, nlevels = 0, upto = 0;
+    HtDevLevel h_levels[HT_MAX_LEVELS];
+    HtDevLevel *d_levels = nullptr;
+    uint64_t arena_stride = 0;  // bytes per frame
+    uint64_t pyr_bytes = 0, windows_per_frame = 0;
+    uint8_t *d_arena = nullptr;
+    std::vector<std::vector<HtResampleJob>> h_gens;  // generation g: jobs that only depend on generations < g
+    std::vector<HtResampleJob *> d_gens;
+    std::vector<uint32_t> gen_blocks;
+    std::vector<HtScanScale> h_scales;
+    HtScanScale *d_scales = nullptr;
+    uint32_t tiles_per_frame = 0;
+
+    // frames
+    uint8_t *d_frames_own = nullptr;
+    size_t d_frames_own_bytes = 0;
+    const uint8_t *d_frames = nullptr;
+    size_t frame_stride = 0;
+    int nframes = 0;
+
+    // scan outputs
+    uint32_t hit_capacity = 1u << 20, queue_capacity = 0, queue_capacity_cfg = 0;
+    ht_hit *d_hits = nullptr;
+    HtQueueEntry *d_queue = nullptr;
+    HtCounters *d_counters = nullptr;
+    HtCounters h_counters;
+    bool enqueued = false;
+
+    // whitebalance / grayscale scratch
+    double *d_scratch = nullptr;
+    size_t d_scratch_bytes = 0;
+
+    // camshift
+    int cs_streams = 0;
+    HtCsState *d_cs = nullptr;
+    uint32_t *d_cs_hist = nullptr;  // per-stream current-frame histogram (4096 bins)
+    ht_cs_trackobj *d_cs_out = nullptr;
+
+    // profiling
+    bool profiling = false;
+    std::vector<HtKernelTimer> timers;
+};
+
+// error helpers -------------------------------------------------------------------------------------------
+ht_status ht_fail(ht_ctx *ctx, ht_status st, const std::string &msg);
+#define HT_HIP(ctx, call)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return ht_fail((ctx), HT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));           \
+    } while (0)
+
+// profiling scope: records a start/stop event pair around kernel launches when ctx->profiling
+struct HtProfScope {
+    ht_ctx *ctx;
+    int idx = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    HtProfScope(ht_ctx *c, const char *name);
+    ~HtProfScope();
+};
+
+// implemented in the .hip files ---------------------------------------------------------------------------
+ht_status ht_launch_pyramid(ht_ctx *ctx, uint32_t flags);   // ht_pyramid.hip
+ht_status ht_launch_scan(ht_ctx *ctx, uint32_t flags);      // ht_scan.hip
+ht_status ht_scan_tile_tables(ht_ctx *ctx);                 // ht_scan.hip: LDS-offset feature table
+ht_status ht_scan_plan_tiles(ht_ctx *ctx);                  // ht_scan.hip: per-scale tiling for the geometry
+ht_status ht_launch_gray_inplace(ht_ctx *ctx, uint8_t *d_rgba, int n, size_t stride);  // ht_pyramid.hip
+ht_status ht_launch_whitebalance(ht_ctx *ctx, double *d_out);                            // ht_pyramid.hip

@@ -1,0 +1,201 @@
+// ht_pyramid.hip — grayscale + image pyramid kernels (gfx950).
+//
+// Reference behaviour (paths under /root/reference/src/):
+//   ccv.grayscale            ccv.js:22-32     g = R*0.3 + G*0.59 + B*0.11 in binary64, Uint8ClampedArray store
+//   pyramid build            ccv.js:113-147   canvas drawImage at 39 levels (+3 shifted variants for levels >= 12)
+//   getWhitebalance          whitebalance.js:5-30
+// drawImage's resampling filter is browser-defined; this repo declares it in oracle/canvas_shim.js (centre-aligned
+// bilinear in binary64, round-half-even store) and the kernels below implement that declaration bit for bit:
+// explicit __dmul_rn/__dadd_rn (never contracted into FMAs), ratios divided on the host.
+//
+// HBM layout: the reference keeps 4-byte RGBA copies of every level but only ever reads byte 0 (ccv.js:171,173,
+// 191-192), so each plane is stored once as 1 byte/pixel (row stride = width rounded up to 4, plane base 256-B
+// aligned) inside a per-frame arena; frames are arena_stride bytes apart.  All kernels take the frame index from
+// blockIdx.y so a whole batch is one launch per dependency generation.
+#include "ht_internal.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t gray_of(uint32_t px) {  // ccv.js:29
+    const double r = (double)(px & 0xffu), g = (double)((px >> 8) & 0xffu), b = (double)((px >> 16) & 0xffu);
+    const double v = __dadd_rn(__dadd_rn(__dmul_rn(r, 0.3), __dmul_rn(g, 0.59)), __dmul_rn(b, 0.11));
+    const int q = (int)__builtin_rint(v);  // round half to even (Uint8ClampedArray)
+    return (uint32_t)min(max(q, 0), 255);
+}
+
+// RGBA -> planar gray (level 0).  ALIGNED: W % 4 == 0, so plane and frame are both linear and 16-byte aligned per
+// group of 4 pixels: one dwordx4 load + one dword store per thread, fully coalesced.
+template <bool GRAY_IN_R>
+__global__ __launch_bounds__(256) void k_gray_linear(const uint8_t *__restrict__ frames, size_t frame_stride,
+                                                     uint8_t *__restrict__ arena, uint64_t arena_stride, uint32_t off0,
+                                                     uint32_t ngroups) {
+    const uint32_t f = blockIdx.y;
+    const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)f * frame_stride);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(arena + (uint64_t)f * arena_stride + off0);
+    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
+        const uint4 p = src[g];
+        uint32_t o;
+        if (GRAY_IN_R)
+            o = (p.x & 0xff) | ((p.y & 0xff) << 8) | ((p.z & 0xff) << 16) | ((p.w & 0xff) << 24);
+        else
+            o = gray_of(p.x) | (gray_of(p.y) << 8) | (gray_of(p.z) << 16) | (gray_of(p.w) << 24);
+        dst[g] = o;
+    }
+}
+
+// General width: 2-D mapping, 4 pixels per thread with dword loads.
+template <bool GRAY_IN_R>
+__global__ __launch_bounds__(256) void k_gray_rows(const uint8_t *__restrict__ frames, size_t frame_stride,
+                                                   uint8_t *__restrict__ arena, uint64_t arena_stride, uint32_t off0, int W,
+                                                   int H, int stride) {
+    const uint32_t f = blockIdx.z;
+    const int x0 = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (y >= H || x0 >= stride) return;
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(frames + (size_t)f * frame_stride) + (size_t)y * W;
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (x0 + k < W) {
+            const uint32_t p = src[x0 + k];
+            o |= (GRAY_IN_R ? (p & 0xff) : gray_of(p)) << (8 * k);
+        }
+    }
+    *reinterpret_cast<uint32_t *>(arena + (uint64_t)f * arena_stride + off0 + (size_t)y * stride + x0) = o;
+}
+
+// ccv.grayscale drop-in: RGBA in place, R=G=B=gray, A kept.
+__global__ __launch_bounds__(256) void k_gray_inplace(uint8_t *__restrict__ frames, size_t frame_stride, uint32_t npix) {
+    uint32_t *p = reinterpret_cast<uint32_t *>(frames + (size_t)blockIdx.y * frame_stride);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const uint32_t v = p[i], g = gray_of(v);
+        p[i] = g | (g << 8) | (g << 16) | (v & 0xff000000u);
+    }
+}
+
+// One generation of drawImage calls.  Block = 128 x 8 destination pixels of one job, thread = 4 pixels of a row.
+__global__ __launch_bounds__(256) void k_resample(const HtResampleJob *__restrict__ jobs, int njobs, uint8_t *__restrict__ arena,
+                                                  uint64_t arena_stride) {
+    // job lookup: block_begin is ascending; everything here is wave-uniform (scalar)
+    int ji = 0;
+    for (int k = 1; k < njobs; k++)
+        if (blockIdx.x >= jobs[k].block_begin) ji = k;
+    const HtResampleJob &J = jobs[ji];
+    const uint32_t lb = blockIdx.x - J.block_begin;
+    const uint32_t by = lb / J.blocks_x, bx = lb - by * J.blocks_x;
+    const int x0 = (int)(bx * 128 + threadIdx.x * 4), y = (int)(by * 8 + threadIdx.y);
+    if (y >= J.ch || x0 >= J.dst_stride) return;
+    uint8_t *frame = arena + (uint64_t)blockIdx.y * arena_stride;
+    const uint8_t *src = frame + J.src_off;
+    uint32_t o = 0;
+    if (y < J.dh) {
+        double fy = __dadd_rn(__dmul_rn((double)y + 0.5, J.ry), -0.5);
+        fy = fy < 0.0 ? 0.0 : fy;
+        const double ymax = (double)(J.sh - 1);
+        fy = fy > ymax ? ymax : fy;
+        const double y0f = floor(fy);
+        const int y0 = (int)y0f, y1 = min(y0 + 1, J.sh - 1);
+        const double ty = __dadd_rn(fy, -y0f), uy = __dadd_rn(1.0, -ty);
+        const uint8_t *r0 = src + (size_t)(J.sy + y0) * J.src_stride + J.sx;
+        const uint8_t *r1 = src + (size_t)(J.sy + y1) * J.src_stride + J.sx;
+        const double xmax = (double)(J.sw - 1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = x0 + k;
+            if (x < J.dw) {
+                double fx = __dadd_rn(__dmul_rn((double)x + 0.5, J.rx), -0.5);
+                fx = fx < 0.0 ? 0.0 : fx;
+                fx = fx > xmax ? xmax : fx;
+                const double x0f = floor(fx);
+                const int xa = (int)x0f, xb = min(xa + 1, J.sw - 1);
+                const double tx = __dadd_rn(fx, -x0f), ux = __dadd_rn(1.0, -tx);
+                const double top = __dadd_rn(__dmul_rn((double)r0[xa], ux), __dmul_rn((double)r0[xb], tx));
+                const double bot = __dadd_rn(__dmul_rn((double)r1[xa], ux), __dmul_rn((double)r1[xb], tx));
+                const double v = __dadd_rn(__dmul_rn(top, uy), __dmul_rn(bot, ty));
+                const int q = (int)__builtin_rint(v);
+                o |= (uint32_t)min(max(q, 0), 255) << (8 * k);
+            }
+        }
+    }
+    *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o;
+}
+
+// per-frame channel sums for getWhitebalance; out[f*4 + c] (u64), zeroed by the host
+__global__ __launch_bounds__(256) void k_channel_sums(const uint8_t *__restrict__ frames, size_t frame_stride, uint32_t npix,
+                                                      unsigned long long *__restrict__ out) {
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(frames + (size_t)blockIdx.y * frame_stride);
+    uint32_t r = 0, g = 0, b = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const uint32_t v = p[i];
+        r += v & 0xff;
+        g += (v >> 8) & 0xff;
+        b += (v >> 16) & 0xff;
+    }
+    unsigned long long rr = r, gg = g, bb = b;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        rr += __shfl_xor(rr, s, 64);
+        gg += __shfl_xor(gg, s, 64);
+        bb += __shfl_xor(bb, s, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[blockIdx.y * 4 + 0], rr);
+        atomicAdd(&out[blockIdx.y * 4 + 1], gg);
+        atomicAdd(&out[blockIdx.y * 4 + 2], bb);
+    }
+}
+
+}  // namespace
+
+ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
+    const bool gray_in_r = (flags & HT_INPUT_GRAY_IN_R) != 0;
+    const HtDevLevel &L0 = c->h_levels[0];
+    {
+        HtProfScope ps(c, "gray");
+        if ((c->W & 3) == 0) {
+            const uint32_t ngroups = (uint32_t)((size_t)c->W * c->H / 4);
+            dim3 grid(std::min<uint32_t>((ngroups + 255) / 256, 2048), c->nframes);
+            if (gray_in_r)
+                hipLaunchKernelGGL(k_gray_linear<true>, grid, dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena,
+                                   c->arena_stride, L0.off[0], ngroups);
+            else
+                hipLaunchKernelGGL(k_gray_linear<false>, grid, dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena,
+                                   c->arena_stride, L0.off[0], ngroups);
+        } else {
+            dim3 grid((L0.stride / 4 + 63) / 64, (c->H + 3) / 4, c->nframes);
+            if (gray_in_r)
+                hipLaunchKernelGGL(k_gray_rows<true>, grid, dim3(64, 4), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena,
+                                   c->arena_stride, L0.off[0], c->W, c->H, L0.stride);
+            else
+                hipLaunchKernelGGL(k_gray_rows<false>, grid, dim3(64, 4), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena,
+                                   c->arena_stride, L0.off[0], c->W, c->H, L0.stride);
+        }
+        HT_HIP(c, hipGetLastError());
+    }
+    for (size_t g = 1; g < c->h_gens.size(); g++) {
+        if (c->gen_blocks[g] == 0) continue;
+        HtProfScope ps(c, "resample");
+        hipLaunchKernelGGL(k_resample, dim3(c->gen_blocks[g], c->nframes), dim3(32, 8), 0, c->stream, c->d_gens[g],
+                           (int)c->h_gens[g].size(), c->d_arena, c->arena_stride);
+        HT_HIP(c, hipGetLastError());
+    }
+    return HT_OK;
+}
+
+ht_status ht_launch_gray_inplace(ht_ctx *c, uint8_t *d_rgba, int n, size_t stride) {
+    HtProfScope ps(c, "gray_inplace");
+    const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
+    hipLaunchKernelGGL(k_gray_inplace, dim3(std::min<uint32_t>((npix + 255) / 256, 2048), n), dim3(256), 0, c->stream, d_rgba, stride, npix);
+    HT_HIP(c, hipGetLastError());
+    return HT_OK;
+}
+
+ht_status ht_launch_whitebalance(ht_ctx *c, double *d_out) {
+    HtProfScope ps(c, "whitebalance");
+    unsigned long long *out = reinterpret_cast<unsigned long long *>(d_out);
+    HT_HIP(c, hipMemsetAsync(out, 0, sizeof(unsigned long long) * 4 * (size_t)c->nframes, c->stream));
+    const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
+    hipLaunchKernelGGL(k_channel_sums, dim3(std::min<uint32_t>((npix + 1023) / 1024, 256), c->nframes), dim3(256), 0, c->stream,
+                       c->d_frames, c->frame_stride, npix, out);
+    HT_HIP(c, hipGetLastError());
+    return HT_OK;
+}

@@ -1,0 +1,547 @@
+// ht_scan.hip — the BBF cascade scan of ccv.detect_objects (reference: /root/reference/src/ccv.js:150-246) for gfx950.
+//
+// What the reference does per pyramid scale i and half-pixel phase q=(dx,dy): slide a 24x24 window over level i in
+// steps of 4 px (origin (4x+2dx, 4y+2dy)); a feature compares single pixels taken from three planes — level i at full
+// window resolution, level i+6 at half, level i+12 (variant q) at quarter resolution — and fires iff
+// min(positive pixels) > max(negative pixels) (ccv.js:189-220, the early exits there never change the outcome);
+// a stage sums alpha[2k + fired_k] sequentially in binary64 and rejects the window if sum < threshold (ccv.js:222).
+//
+// MI355X mapping (no MFMA: this is byte gathers + compares, LDS-issue bound):
+//   * k_scan_tiles — one workgroup per (frame, scale, tile).  The 4 phases are just the half-step grid
+//     (X', Y') = (2x+dx, 2y+dy), so a tile is a dense rectangle of X' x Y' windows.  The three planes are staged in
+//     LDS in a "unified-base" layout: plane 0 at 1 B/px with row pitch P, plane 1 at 2 B/px with row pitch 2P, and the
+//     four quarter-res variants interleaved into one half-step grid in the odd bytes of the plane-1 cells.  Then
+//     every window has ONE base address B = 2*(Y'*P + X') and every feature point is base + a per-feature constant,
+//     so the inner loop is {s_load feature (uniform), v_add, ds_read_u8, v_min/v_max}; adjacent lanes (adjacent X')
+//     read LDS at a 2-byte stride on every plane: conflict-free.  Windows that pass a stage are compacted
+//     (ballot + LDS counter) so later stages run on dense lanes.  Per-lane sums are sequential binary64 adds in the
+//     reference's order, hence bit-exact.
+//   * k_scan_deep — survivors of the first `split` stages (a fraction of a percent of all windows) go through a
+//     global queue to one wavefront per window with the stage's features spread across lanes.  Stage decisions use
+//     exact integer sums of alpha*1e8 (the trained alphas/thresholds are 8-digit decimals; a different summation
+//     order cannot change an integer sum), falling back to the sequential binary64 sum on an exact tie and for the
+//     reported confidence of full survivors.
+//   * k_scan_simple — one thread per window straight from HBM; slow, kept as an independent cross-check.
+#include <algorithm>
+#include <cstring>
+
+#include "ht_internal.h"
+
+namespace {
+
+// tile geometry (window = 24x24, see ht_scan_tile_tables for the check)
+constexpr int TXH = 64;                 // tile width  in half-window steps X'
+constexpr int TYH = 32;                 // tile height in half-window steps Y'
+constexpr int NT = 256;                 // threads per workgroup
+constexpr int PITCH0 = 2 * TXH + 24;    // 152: plane-0 bytes per LDS row
+constexpr int ROWS0 = 2 * TYH + 22;     // 86
+constexpr int P0_BYTES = PITCH0 * ROWS0;  // 13072
+constexpr int GH = TYH + 11;               // plane-1 / plane-2 half-step grid: 75 x 43 cells of 2 bytes
+constexpr int G_PITCH = 2 * PITCH0;          // 304
+constexpr int P12_BASE = P0_BYTES;
+constexpr int LDS_TILE_BYTES = P0_BYTES + GH * G_PITCH;  // 26144
+constexpr int MAXWIN = TXH * TYH;            // 2048 windows per tile
+static_assert(PITCH0 % 4 == 0 && P0_BYTES % 4 == 0, "alignment");
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// offset j of a packed u16x2 table held in scalar registers
+#define HT_OFF(tab, j) (((j) & 1) ? ((tab)[(j) >> 1] >> 16) : ((tab)[(j) >> 1] & 0xffffu))
+#define HT_RD(tab, j) ((uint32_t)lds[B + HT_OFF(tab, j)])
+
+// One stage for one window held by this lane; F/count are wave-uniform, so the feature record is fetched with scalar
+// loads and every branch below is a scalar branch.  Sequential binary64 accumulation in feature order == ccv.js:186-221.
+__device__ __forceinline__ double eval_stage_lds(const uint8_t *lds, uint32_t B, const HtTileFeature *__restrict__ F, uint32_t count) {
+    double sum = 0.0;
+    for (uint32_t k = 0; k < count; k++) {
+        const uint4 P4 = *reinterpret_cast<const uint4 *>(F[k].po);
+        const uint4 N4 = *reinterpret_cast<const uint4 *>(F[k].no);
+        const uint4 A4 = *reinterpret_cast<const uint4 *>(F[k].a);
+        const uint32_t np = F[k].np, nn = F[k].nn;
+        const uint32_t po[4] = {P4.x, P4.y, P4.z, P4.w}, no[4] = {N4.x, N4.y, N4.z, N4.w};
+        uint32_t pmin = HT_RD(po, 0), nmax = HT_RD(no, 0);
+        if (np > 1) {
+            pmin = min(pmin, HT_RD(po, 1));
+            if (np > 2) {
+                pmin = min(pmin, HT_RD(po, 2));
+                if (np > 3) {
+                    pmin = min(pmin, HT_RD(po, 3));
+                    if (np > 4) {
+                        pmin = min(pmin, HT_RD(po, 4));
+                        if (np > 5) {
+                            pmin = min(pmin, HT_RD(po, 5));
+                            if (np > 6) {
+                                pmin = min(pmin, HT_RD(po, 6));
+                                if (np > 7) pmin = min(pmin, HT_RD(po, 7));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (nn > 1) {
+            nmax = max(nmax, HT_RD(no, 1));
+            if (nn > 2) {
+                nmax = max(nmax, HT_RD(no, 2));
+                if (nn > 3) {
+                    nmax = max(nmax, HT_RD(no, 3));
+                    if (nn > 4) {
+                        nmax = max(nmax, HT_RD(no, 4));
+                        if (nn > 5) {
+                            nmax = max(nmax, HT_RD(no, 5));
+                            if (nn > 6) {
+                                nmax = max(nmax, HT_RD(no, 6));
+                                if (nn > 7) nmax = max(nmax, HT_RD(no, 7));
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        const bool fire = pmin > nmax;
+        sum = __dadd_rn(sum, __hiloint2double((int)(fire ? A4.w : A4.y), (int)(fire ? A4.z : A4.x)));
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(NT) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+                                                   const HtDevLevel *__restrict__ levels, const HtScanScale *__restrict__ scales,
+                                                   int nscales, const HtTileFeature *__restrict__ feats,
+                                                   const HtDevStage *__restrict__ stages, int nstages, int split,
+                                                   uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
+                                                   uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
+                                                   HtCounters *__restrict__ ctr) {
+    __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TILE_BYTES];
+    __shared__ uint16_t qbuf[2][MAXWIN];
+    __shared__ uint32_t s_nout;
+    __shared__ uint32_t s_qbase;
+
+    // XCD-aware tile order: consecutive tiles (same frame / scale, shared halos) stay on one XCD's L2.
+    const uint32_t nb = gridDim.x, chunk = nb >> 3;  // gridDim.x is a multiple of 8
+    const uint32_t t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if (t >= total_tiles) return;
+    const uint32_t frame = t / tiles_per_frame, lt = t - frame * tiles_per_frame;
+    int si = 0;
+    for (int k = 1; k < nscales; k++)
+        if (lt >= scales[k].tile_begin) si = k;
+    const HtScanScale S = scales[si];
+    const uint32_t tl = lt - S.tile_begin;
+    const int tyi = (int)(tl / (uint32_t)S.ntx), txi = (int)(tl - (uint32_t)tyi * S.ntx);
+    const int X0 = txi * S.tw2, Y0 = tyi * S.th2;           // tile origin in half-window steps
+    const int tw = min(S.tw2, 2 * S.qw - X0), th = min(S.th2, 2 * S.qh - Y0);
+    const HtDevLevel L0 = levels[S.l0], L1 = levels[S.l1], L2 = levels[S.l2];
+    const uint8_t *fbase = arena + (uint64_t)frame * arena_stride;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+
+    // ---- stage the three planes into LDS --------------------------------------------------------------------
+    {   // plane 0: level i, origin (2*X0, 2*Y0), rows of PITCH0 bytes as aligned dwords
+        const uint8_t *p0 = fbase + L0.off[0];
+        const int gx0 = 2 * X0, gy0 = 2 * Y0;
+        const int rows = 2 * th + 22;
+        for (int i = (int)tid; i < rows * (PITCH0 / 4); i += NT) {
+            const int r = i / (PITCH0 / 4), c4 = (i - r * (PITCH0 / 4)) * 4;
+            const int gy = gy0 + r, gx = gx0 + c4;
+            uint32_t v = 0;
+            if (gy < L0.h && gx < L0.stride) v = *reinterpret_cast<const uint32_t *>(p0 + (size_t)gy * L0.stride + gx);
+            *reinterpret_cast<uint32_t *>(&lds[r * PITCH0 + c4]) = v;
+        }
+        // planes 1 + 2: half-step grid cell (X, Y) = { level i+6 pixel (X0+X, Y0+Y),  variant q pixel ((X0+X)>>1, (Y0+Y)>>1) }
+        // with q = ((Y0+Y)&1)*2 + ((X0+X)&1)   (ccv.js:132-146: variant q is level i+6 shifted by (dx,dy) then halved)
+        const uint8_t *p1 = fbase + L1.off[0];
+        const int gw = tw + 11, gh = th + 11;
+        for (int Y = (int)(tid >> 6); Y < gh; Y += NT / 64) {
+            const int ay = Y0 + Y;
+            const int y2 = ay >> 1;
+            for (int X = (int)lane; X < gw; X += 64) {
+                const int ax = X0 + X;
+                const int q = ((ay & 1) << 1) | (ax & 1), x2 = ax >> 1;
+                uint32_t a = 0, b = 0;
+                if (ay < L1.h && ax < L1.w) a = p1[(size_t)ay * L1.stride + ax];
+                const uint32_t o2 = q == 0 ? L2.off[0] : (q == 1 ? L2.off[1] : (q == 2 ? L2.off[2] : L2.off[3]));
+                if (y2 < L2.h && x2 < L2.w) b = fbase[o2 + (size_t)y2 * L2.stride + x2];
+                *reinterpret_cast<uint16_t *>(&lds[P12_BASE + Y * G_PITCH + 2 * X]) = (uint16_t)(a | (b << 8));
+            }
+        }
+    }
+    if (tid == 0) s_nout = 0;
+    __syncthreads();
+
+    // ---- cascade with per-stage compaction -------------------------------------------------------------------
+    uint32_t n_in = (uint32_t)(S.tw2 * th);  // stage 0 enumerates id = Y'*tw2 + X' (X' >= tw is masked off)
+    uint32_t qoff = 0;                        // start of the live entries inside qbuf[cur]
+    int cur = 0;
+    bool pushed = (split >= nstages);
+    for (int s = 0; s < nstages; s++) {
+        if (s == split && !pushed) {
+            // hand the survivors of the first `split` stages to k_scan_deep through the global queue
+            pushed = true;
+            if (tid == 0) s_qbase = atomicAdd(&ctr->nqueue, n_in);
+            __syncthreads();
+            const uint32_t qb = s_qbase;
+            const uint32_t room = qb < queue_cap ? queue_cap - qb : 0u;
+            const uint32_t npush = min(n_in, room);
+            for (uint32_t i = tid; i < npush; i += NT) {
+                const uint32_t id = qbuf[cur][qoff + i];
+                const uint32_t yy = (id * S.div_magic) >> 20, xx = id - yy * (uint32_t)S.tw2;
+                const uint32_t ax = (uint32_t)X0 + xx, ay = (uint32_t)Y0 + yy;
+                HtQueueEntry e;
+                e.frame = frame;
+                e.x = (uint16_t)(ax >> 1);
+                e.y = (uint16_t)(ay >> 1);
+                e.scale = (uint8_t)S.l0;
+                e.q = (uint8_t)(((ay & 1u) << 1) | (ax & 1u));
+                e.pad = 0;
+                e.pad2 = 0;
+                queue[qb + i] = e;
+            }
+            if (npush == n_in) return;  // the common case
+            if (tid == 0) atomicAdd(&ctr->queue_inline, n_in - npush);
+            qoff += npush;  // queue full: finish the remaining survivors right here
+            n_in -= npush;
+        }
+        const HtDevStage st = stages[s];
+        const HtTileFeature *F = feats + st.first;
+        const bool last = (s == nstages - 1);
+        uint32_t n_valid = 0;
+        for (uint32_t base = 0; base < n_in; base += NT) {
+            const uint32_t pos = base + tid;
+            bool valid = pos < n_in;
+            uint32_t id = 0;
+            if (valid) id = (s == 0) ? pos : (uint32_t)qbuf[cur][qoff + pos];
+            const uint32_t yy = (id * S.div_magic) >> 20, xx = id - yy * (uint32_t)S.tw2;
+            valid = valid && xx < (uint32_t)tw;
+            const uint32_t B = 2u * (yy * PITCH0 + xx);
+            const double sum = eval_stage_lds(lds, valid ? B : 0u, F, st.count);
+            const bool pass = valid && !(sum < st.threshold);  // ccv.js:222
+            const unsigned long long m = __ballot(pass);
+            if (s == 0) n_valid += __popcll(__ballot(valid));
+            if (m) {
+                const uint32_t cnt = __popcll(m);
+                const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                uint32_t b0 = 0;
+                if (!last) {
+                    if (lane == 0) b0 = atomicAdd(&s_nout, cnt);
+                    b0 = __shfl(b0, 0, 64);
+                    if (pass) qbuf[cur ^ 1][b0 + pre] = (uint16_t)id;
+                } else {
+                    if (lane == 0) b0 = atomicAdd(&ctr->nhits, cnt);
+                    b0 = __shfl(b0, 0, 64);
+                    if (pass && b0 + pre < hit_cap) {
+                        const uint32_t ax = (uint32_t)X0 + xx, ay = (uint32_t)Y0 + yy;
+                        ht_hit h;
+                        h.frame = frame;
+                        h.x = (uint16_t)(ax >> 1);
+                        h.y = (uint16_t)(ay >> 1);
+                        h.scale = (uint8_t)S.l0;
+                        h.q = (uint8_t)(((ay & 1u) << 1) | (ax & 1u));
+                        h.reserved0 = 0;
+                        h.reserved1 = 0;
+                        h.sum = sum;  // ccv.js:233
+                        hits[b0 + pre] = h;
+                    }
+                    if (lane == 0) atomicAdd(&ctr->stage_in[nstages], (unsigned long long)cnt);
+                }
+            }
+        }
+        if (s == 0) {
+            if (lane == 0 && n_valid) atomicAdd(&ctr->stage_in[0], (unsigned long long)n_valid);
+        } else if (tid == 0) {
+            atomicAdd(&ctr->stage_in[s], (unsigned long long)n_in);
+        }
+        __syncthreads();
+        n_in = s_nout;
+        __syncthreads();
+        if (tid == 0) s_nout = 0;
+        cur ^= 1;
+        qoff = 0;
+        if (n_in == 0) return;
+        // s_nout reset is ordered before its next use by the __syncthreads at the end of the next stage's loop body:
+        // the next atomicAdd(&s_nout) can only come after every thread passed this point, but tid 0 might still be
+        // about to write 0 -> make the reset visible first.
+        __syncthreads();
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// deep kernel: one wavefront per surviving window, features across lanes
+
+// A window's three plane origins as 32-bit offsets from the frame's arena base, plus the row strides.  Plain scalars
+// passed by value on purpose: a struct of arrays indexed by the per-lane plane number gets demoted to LDS scratch.
+#define HT_WIN_ARGS const uint8_t *fb, uint32_t o0, uint32_t o1, uint32_t o2, int s0, int s1, int s2
+#define HT_WIN_PASS fb, o0, o1, o2, s0, s1, s2
+#define HT_WIN_SETUP(fbase_, levels_, next_, scale_, q_, x_, y_)                                                      \
+    const uint8_t *fb = (fbase_);                                                                                     \
+    uint32_t o0, o1, o2;                                                                                              \
+    int s0, s1, s2;                                                                                                   \
+    {                                                                                                                 \
+        const HtDevLevel L0_ = (levels_)[(scale_)], L1_ = (levels_)[(scale_) + (next_)], L2_ = (levels_)[(scale_) + 2 * (next_)]; \
+        const uint32_t dx_ = (q_)&1u, dy_ = (q_) >> 1;                                                                \
+        const uint32_t v2_ = (q_) == 0 ? L2_.off[0] : ((q_) == 1 ? L2_.off[1] : ((q_) == 2 ? L2_.off[2] : L2_.off[3])); \
+        s0 = L0_.stride, s1 = L1_.stride, s2 = L2_.stride;                                                            \
+        o0 = L0_.off[0] + (4 * (y_) + 2 * dy_) * (uint32_t)s0 + (4 * (x_) + 2 * dx_); /* ccv.js:180,235 */            \
+        o1 = L1_.off[0] + (2 * (y_) + dy_) * (uint32_t)s1 + (2 * (x_) + dx_);         /* ccv.js:180,236 */            \
+        o2 = v2_ + (y_) * (uint32_t)s2 + (x_);                                        /* ccv.js:179,237 */            \
+    }
+
+__device__ __forceinline__ bool deep_fire(const HtDeepFeature *__restrict__ fp, HT_WIN_ARGS, uint32_t maxpts) {
+    // six 8-byte coordinate arrays, one 64-bit load each; byte j = slot j (slots >= np/nn repeat slot 0)
+    const unsigned long long *c = reinterpret_cast<const unsigned long long *>(fp);
+    unsigned long long px = c[0], py = c[1], pz = c[2], nx = c[3], ny = c[4], nz = c[5];
+    uint32_t pmin = 255u, nmax = 0u;
+    for (uint32_t j = 0; j < maxpts; j++) {
+        const uint32_t zp = (uint32_t)pz & 0xffu, zn = (uint32_t)nz & 0xffu;
+        const uint32_t po = zp == 0 ? o0 : (zp == 1 ? o1 : o2), ps = (uint32_t)(zp == 0 ? s0 : (zp == 1 ? s1 : s2));
+        const uint32_t no = zn == 0 ? o0 : (zn == 1 ? o1 : o2), ns = (uint32_t)(zn == 0 ? s0 : (zn == 1 ? s1 : s2));
+        pmin = min(pmin, (uint32_t)fb[po + ((uint32_t)py & 0xffu) * ps + ((uint32_t)px & 0xffu)]);
+        nmax = max(nmax, (uint32_t)fb[no + ((uint32_t)ny & 0xffu) * ns + ((uint32_t)nx & 0xffu)]);
+        px >>= 8, py >>= 8, pz >>= 8, nx >>= 8, ny >>= 8, nz >>= 8;
+    }
+    return pmin > nmax;
+}
+
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// sequential binary64 stage sum in the reference's order: fire bits in parallel, adds in order (all lanes redundantly)
+__device__ __forceinline__ double deep_stage_sum_exact(const HtDeepFeature *__restrict__ F, uint32_t count, uint32_t maxpts,
+                                                       HT_WIN_ARGS, uint32_t lane) {
+    double sum = 0.0;
+    for (uint32_t kb = 0; kb < count; kb += 64) {
+        const uint32_t k = kb + lane;
+        bool fire = false;
+        if (k < count) fire = deep_fire(&F[k], HT_WIN_PASS, maxpts);
+        const unsigned long long m = __ballot(fire);
+        const uint32_t nn = min(64u, count - kb);
+        for (uint32_t t = 0; t < nn; t++) {
+            const HtDeepFeature &f = F[kb + t];
+            sum = __dadd_rn(sum, ((m >> t) & 1ull) ? f.a1 : f.a0);
+        }
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(256) void k_scan_deep(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+                                                   const HtDevLevel *__restrict__ levels, int next,
+                                                   const HtDeepFeature *__restrict__ feats, const HtDevStage *__restrict__ stages,
+                                                   int nstages, int split, int use_int, const HtQueueEntry *__restrict__ queue,
+                                                   uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
+                                                   HtCounters *__restrict__ ctr) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = min(ctr->nqueue, queue_cap);
+    for (uint32_t e = wave; e < n; e += nwaves) {
+        const HtQueueEntry ent = queue[e];
+        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x, (uint32_t)ent.y)
+        bool alive = true;
+        double conf = 0.0;
+        for (int j = split; j < nstages; j++) {
+            const HtDevStage st = stages[j];
+            const HtDeepFeature *F = feats + st.first;
+            if (lane == 0) atomicAdd(&ctr->stage_in[j], 1ull);
+            bool need_exact = true;
+            if (use_int) {
+                long long acc = 0;
+                for (uint32_t k = lane; k < st.count; k += 64) {
+                    const HtDeepFeature &f = F[k];
+                    acc += deep_fire(&f, HT_WIN_PASS, st.maxpts) ? f.a1i : f.a0i;
+                }
+                const long long Ssum = wave_sum_i64(acc);
+                if (Ssum < st.thri) {  // sum < threshold decided exactly, independent of summation order
+                    alive = false;
+                    break;
+                }
+                need_exact = (Ssum == st.thri) || (j == nstages - 1);
+            }
+            if (need_exact) {
+                const double sum = deep_stage_sum_exact(F, st.count, st.maxpts, HT_WIN_PASS, lane);
+                if (sum < st.threshold) {  // ccv.js:222
+                    alive = false;
+                    break;
+                }
+                conf = sum;
+            }
+        }
+        if (alive && lane == 0) {
+            atomicAdd(&ctr->stage_in[nstages], 1ull);
+            const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
+            if (pos < hit_cap) {
+                ht_hit h;
+                h.frame = ent.frame;
+                h.x = ent.x;
+                h.y = ent.y;
+                h.scale = ent.scale;
+                h.q = ent.q;
+                h.reserved0 = 0;
+                h.reserved1 = 0;
+                h.sum = conf;
+                hits[pos] = h;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------------------------------------------
+// simple kernel: one thread per window, every stage, straight from HBM (independent cross-check of the tiled path)
+
+__global__ __launch_bounds__(256) void k_scan_simple(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+                                                     const HtDevLevel *__restrict__ levels, int next,
+                                                     const HtScanScale *__restrict__ scales, int nscales, uint32_t windows_per_frame,
+                                                     const HtDeepFeature *__restrict__ feats, const HtDevStage *__restrict__ stages,
+                                                     int nstages, ht_hit *__restrict__ hits, uint32_t hit_cap,
+                                                     HtCounters *__restrict__ ctr) {
+    const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t frame = blockIdx.y;
+    const uint32_t lane = threadIdx.x & 63u;
+    bool alive = wi < windows_per_frame;
+    int si = 0;
+    for (int k = 1; k < nscales; k++)
+        if (wi >= scales[k].win_begin) si = k;
+    const HtScanScale S = scales[si];
+    const uint32_t li = alive ? wi - S.win_begin : 0u;
+    const uint32_t per = (uint32_t)(S.qw * S.qh);
+    const uint32_t q = li / per, r = li - q * per, y = r / (uint32_t)S.qw, x = r - y * (uint32_t)S.qw;
+    HT_WIN_SETUP(arena + (uint64_t)frame * arena_stride, levels, next, (uint32_t)S.l0, q, x, y)
+    double sum = 0.0;
+    for (int j = 0; j < nstages; j++) {
+        const unsigned long long m = __ballot(alive);
+        if (!m) break;
+        if (lane == 0) atomicAdd(&ctr->stage_in[j], (unsigned long long)__popcll(m));
+        const HtDevStage st = stages[j];
+        const HtDeepFeature *F = feats + st.first;
+        sum = 0.0;
+        if (alive) {
+            for (uint32_t k = 0; k < st.count; k++) {
+                const HtDeepFeature &f = F[k];
+                sum = __dadd_rn(sum, deep_fire(&f, HT_WIN_PASS, st.maxpts) ? f.a1 : f.a0);
+            }
+            if (sum < st.threshold) alive = false;
+        }
+    }
+    if (alive) {
+        atomicAdd(&ctr->stage_in[nstages], 1ull);
+        const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
+        if (pos < hit_cap) {
+            ht_hit h;
+            h.frame = frame;
+            h.x = (uint16_t)x;
+            h.y = (uint16_t)y;
+            h.scale = (uint8_t)S.l0;
+            h.q = (uint8_t)q;
+            h.reserved0 = 0;
+            h.reserved1 = 0;
+            h.sum = sum;
+            hits[pos] = h;
+        }
+    }
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------------------------------------------------
+// host side
+
+// LDS-offset form of every feature for k_scan_tiles (unified-base layout, see the file header)
+ht_status ht_scan_tile_tables(ht_ctx *c) {
+    std::vector<HtTileFeature> tf(c->nfeat);
+    const bool tile_ok = (c->cw == 24 && c->ch == 24);
+    for (uint32_t k = 0; k < c->nfeat; k++) {
+        const HtBlobFeature &f = c->h_feats[k];
+        HtTileFeature &t = tf[k];
+        std::memset(&t, 0, sizeof(t));
+        auto off = [](int x, int y, int z) -> uint16_t {
+            if (z == 0) return (uint16_t)(y * PITCH0 + x);                       // level i: 1 B/px, pitch P
+            if (z == 1) return (uint16_t)(P12_BASE + y * G_PITCH + 2 * x);       // level i+6: 2 B/px, pitch 2P
+            return (uint16_t)(P12_BASE + 1 + 4 * y * PITCH0 + 4 * x);            // level i+12 variants: odd bytes, 4 B/px, pitch 4P
+        };
+        for (int q = 0; q < f.size; q++) {
+            if (f.pz[q] >= 0) {
+                t.po[t.np >> 1] |= (uint32_t)off(f.px[q], f.py[q], f.pz[q]) << (16 * (t.np & 1));
+                t.np++;
+            }
+            if (f.nz[q] >= 0) {
+                t.no[t.nn >> 1] |= (uint32_t)off(f.nx[q], f.ny[q], f.nz[q]) << (16 * (t.nn & 1));
+                t.nn++;
+            }
+        }
+        std::memcpy(&t.a[0], &f.alpha[0], 8);
+        std::memcpy(&t.a[2], &f.alpha[1], 8);
+    }
+    (void)tile_ok;
+    HT_HIP(c, hipMalloc(&c->d_tile_feats, tf.size() * sizeof(HtTileFeature)));
+    HT_HIP(c, hipMemcpy(c->d_tile_feats, tf.data(), tf.size() * sizeof(HtTileFeature), hipMemcpyHostToDevice));
+    return HT_OK;
+}
+
+ht_status ht_scan_plan_tiles(ht_ctx *c) {
+    c->h_scales.clear();
+    c->windows_per_frame = 0;
+    uint32_t tiles = 0;
+    for (int i = 0; i < c->upto; i++) {  // ccv.js:154
+        HtScanScale S;
+        std::memset(&S, 0, sizeof(S));
+        S.l0 = i;
+        S.l1 = i + c->next;
+        S.l2 = i + 2 * c->next;
+        S.qw = c->h_levels[S.l2].w - (int)(c->cw / 4);  // ccv.js:155
+        S.qh = c->h_levels[S.l2].h - (int)(c->ch / 4);  // ccv.js:156
+        if (S.qw <= 0 || S.qh <= 0) continue;
+        S.ntx = (2 * S.qw + TXH - 1) / TXH;
+        S.tw2 = (2 * S.qw + S.ntx - 1) / S.ntx;
+        S.tw2 += S.tw2 & 1;  // even, so plane-0 tile rows start on a dword
+        S.nty = (2 * S.qh + TYH - 1) / TYH;
+        S.th2 = (2 * S.qh + S.nty - 1) / S.nty;
+        S.th2 += S.th2 & 1;
+        S.ntx = (2 * S.qw + S.tw2 - 1) / S.tw2;
+        S.nty = (2 * S.qh + S.th2 - 1) / S.th2;
+        S.tile_begin = tiles;
+        S.div_magic = ((1u << 20) + (uint32_t)S.tw2 - 1) / (uint32_t)S.tw2;
+        if (c->windows_per_frame + 4ull * S.qw * S.qh > 0xffffffffull) return ht_fail(c, HT_ERR_INVALID, "frame too large");
+        S.win_begin = (uint32_t)c->windows_per_frame;
+        tiles += (uint32_t)(S.ntx * S.nty);
+        c->windows_per_frame += 4ull * (uint64_t)S.qw * (uint64_t)S.qh;
+        c->h_scales.push_back(S);
+    }
+    c->tiles_per_frame = tiles;
+    if (!c->h_scales.empty()) {
+        HT_HIP(c, hipMalloc(&c->d_scales, c->h_scales.size() * sizeof(HtScanScale)));
+        HT_HIP(c, hipMemcpy(c->d_scales, c->h_scales.data(), c->h_scales.size() * sizeof(HtScanScale), hipMemcpyHostToDevice));
+    }
+    return HT_OK;
+}
+
+ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
+    if (c->h_scales.empty() || c->tiles_per_frame == 0) return HT_OK;  // image too small for any window
+    const int nscales = (int)c->h_scales.size();
+    const bool tile_ok = (c->cw == 24 && c->ch == 24);
+    if ((flags & HT_SCAN_SIMPLE) || !tile_ok) {
+        HtProfScope ps(c, "scan_simple");
+        dim3 grid((uint32_t)((c->windows_per_frame + 255) / 256), c->nframes);
+        hipLaunchKernelGGL(k_scan_simple, grid, dim3(256), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next, c->d_scales,
+                           nscales, (uint32_t)c->windows_per_frame, c->d_deep_feats, c->d_stages, (int)c->nstages, c->d_hits,
+                           c->hit_capacity, c->d_counters);
+        HT_HIP(c, hipGetLastError());
+        return HT_OK;
+    }
+    const int split = (flags & HT_SCAN_NO_SPLIT) ? (int)c->nstages : (int)c->split_stage;
+    const uint64_t total64 = (uint64_t)c->tiles_per_frame * (uint64_t)c->nframes;
+    if (total64 > 0x7fffff00ull) return ht_fail(c, HT_ERR_INVALID, "ht_detect: batch too large for one launch");
+    const uint32_t total = (uint32_t)total64;
+    {
+        HtProfScope ps(c, "scan_tiles");
+        hipLaunchKernelGGL(k_scan_tiles, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
+                           c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->tiles_per_frame, total, c->d_queue,
+                           c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters);
+        HT_HIP(c, hipGetLastError());
+    }
+    if (split < (int)c->nstages) {
+        HtProfScope ps(c, "scan_deep");
+        hipLaunchKernelGGL(k_scan_deep, dim3(1024), dim3(256), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
+                           c->d_deep_feats, c->d_stages, (int)c->nstages, split, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity,
+                           c->d_hits, c->hit_capacity, c->d_counters);
+        HT_HIP(c, hipGetLastError());
+    }
+    return HT_OK;
+}

@@ -1,0 +1,187 @@
+/*
+ * headtrackr_hip.h — C ABI of libheadtrackr_hip.so: the MI355X (gfx950) implementation of headtrackr's per-frame
+ * detect / track hot path.
+ *
+ * The reference (auduno/headtrackr) has no FFI; its boundary is the set of JavaScript functions that
+ * facetrackr.Tracker calls once per frame.  Every entry point below names the reference interface it replaces
+ * (paths are /root/reference/src/...).  The N-API shim (headtrackr_amd/csrc/ht_napi.cc) and the JS facade
+ * (headtrackr_amd/js/headtrackr.js) bind exactly these symbols; INTEGRATION.md shows the binding.
+ *
+ * Conventions: plain C, no exceptions; every function returns ht_status (0 = OK) and records a message readable
+ * with ht_last_error(); the caller owns every buffer it passes; a ctx is bound to one GPU and is not thread-safe
+ * (one call in flight per ctx).  Host buffers may be pageable; *_device entry points take device pointers and never
+ * copy.  All work is enqueued on one HIP stream (the caller's, if given in ht_config.stream).
+ */
+#ifndef HEADTRACKR_HIP_H
+#define HEADTRACKR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HT_ABI_VERSION 1
+#define HT_MAX_LEVELS 96
+
+typedef int32_t ht_status;
+enum {
+    HT_OK = 0,
+    HT_ERR_INVALID = -1,   /* bad argument / unsupported geometry */
+    HT_ERR_HIP = -2,       /* a HIP runtime call failed (message has the HIP error string) */
+    HT_ERR_NOMEM = -3,     /* host or device allocation failed */
+    HT_ERR_CAPACITY = -4,  /* an output did not fit the caller's buffer (results truncated, counts are exact) */
+    HT_ERR_NO_DEVICE = -5, /* no usable gfx950 device */
+    HT_ERR_STATE = -6      /* call sequence error (e.g. detect before frames were bound) */
+};
+
+typedef struct ht_ctx ht_ctx;
+
+/* flags for ht_detect_* */
+enum {
+    HT_INPUT_RGBA = 0,      /* colour frame: ccv.grayscale (ccv.js:22-32) is fused into the pyramid build */
+    HT_INPUT_GRAY_IN_R = 1, /* byte 0 of each pixel is already gray: exactly what ccv.detect_objects reads (ccv.js:115,171) */
+    HT_SCAN_FUSED_TAIL = 0, /* default scan schedule */
+    HT_SCAN_NO_SPLIT = 2,   /* run every cascade stage in the tile kernel (no second "deep" kernel); debugging / A-B */
+    HT_SCAN_SIMPLE = 4      /* one thread per window straight from HBM (slow reference kernel); debugging / A-B */
+};
+
+typedef struct ht_config {
+    uint32_t struct_size;   /* = sizeof(ht_config) */
+    int32_t device;         /* HIP device ordinal */
+    int32_t interval;       /* ccv.detect_objects `interval` (facetrackr.js:148 passes 5) */
+    uint32_t hit_capacity;  /* max raw hits kept per batch (0 = default 1<<20) */
+    void *stream;           /* hipStream_t to enqueue on; NULL = library-owned non-blocking stream */
+    uint32_t queue_capacity;/* survivors handed from the tile kernel to the deep kernel per batch (0 = auto) */
+    uint32_t flags;         /* reserved, 0 */
+} ht_config;
+
+/* One raw detection = one element of ccv.detect_objects' `seq` (ccv.js:227-234) in index form:
+ * rect = { x:(4*x+2*(q&1))*s, y:(4*y+2*(q>>1))*s, width:cw*s, height:ch*s, confidence:sum }, s = scale^i. */
+typedef struct ht_hit {
+    uint32_t frame;
+    uint16_t x, y;     /* window index on the quarter-resolution plane */
+    uint8_t scale;     /* i, ccv.js:154 */
+    uint8_t q;         /* half-pixel phase, ccv.js:151-152,178 */
+    uint16_t reserved0;
+    uint32_t reserved1;
+    double sum;        /* last stage's sum (binary64, accumulated in the reference's order) */
+} ht_hit;
+
+typedef struct ht_rect { /* element of detect_objects' result (ccv.js:228-233 raw, 297-302 grouped) */
+    double x, y, width, height, confidence;
+    int32_t neighbors;
+    int32_t reserved;
+} ht_rect;
+
+typedef struct ht_plane_info {
+    int32_t width, height; /* canvas size of the pyramid level */
+    int32_t stride;        /* bytes per row in the device arena */
+    int32_t present;       /* 0 if this (level, slot) does not exist */
+    uint64_t offset;       /* byte offset inside one frame's arena */
+} ht_plane_info;
+
+typedef struct ht_cs_rect { int32_t x, y, width, height; } ht_cs_rect;
+
+/* camshift.Tracker's persistent per-stream state (camshift.js:153-160): lives on the device, one per stream. */
+typedef struct ht_cs_trackobj { /* camshift.TrackObj, camshift.js:362-378 (+ the search window, camshift.js:162-165) */
+    double x, y, width, height, angle;
+    int32_t sw_x, sw_y, sw_width, sw_height;
+} ht_cs_trackobj;
+
+typedef struct ht_kernel_time { /* per-kernel device time of the last ht_detect_* call when profiling is on */
+    char name[32];
+    double ms;
+    uint32_t launches;
+    uint32_t reserved;
+} ht_kernel_time;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+
+/* Creates a context on cfg->device holding the cascade (an "HTCB" blob, see headtrackr_amd/js/cascade_pack.js)
+ * = the `cascade` argument of ccv.detect_objects (ccv.js:109; data: cascade.js:19). */
+ht_status ht_create(const ht_config *cfg, const void *cascade_blob, size_t cascade_len, ht_ctx **out);
+void ht_destroy(ht_ctx *ctx);
+/* Message of the last failure on ctx (ctx == NULL: last failure of ht_create on this thread). Never NULL. */
+const char *ht_last_error(const ht_ctx *ctx);
+int32_t ht_abi_version(void);
+
+/* ---- geometry ------------------------------------------------------------------------------------------ */
+
+/* Fixes frame size and batch capacity; (re)allocates the pyramid arena.  level_dims (optional, 2*nlevels int32:
+ * w0,h0,w1,h1,...) lets a JavaScript host pass the sizes V8 computed with Math.pow/Math.floor (ccv.js:119-120,
+ * 126-127); NULL = computed here (identical for interval 5, see oracle/ht_oracle.c HO_V8_SCALE6_POW). */
+ht_status ht_set_geometry(ht_ctx *ctx, int32_t width, int32_t height, int32_t max_batch, const int32_t *level_dims,
+                          int32_t nlevels);
+int32_t ht_num_levels(const ht_ctx *ctx);
+ht_status ht_plane(const ht_ctx *ctx, int32_t level, int32_t slot, ht_plane_info *out);
+uint64_t ht_windows_per_frame(const ht_ctx *ctx);   /* sliding windows scanned per frame */
+uint64_t ht_pyramid_bytes_per_frame(const ht_ctx *ctx); /* sum of w*h over all planes (gray bytes) */
+
+/* ---- frames -------------------------------------------------------------------------------------------- */
+
+/* Copies n RGBA frames (frame_stride bytes apart, rows packed) from host memory into the ctx's device buffer. */
+ht_status ht_upload_frames(ht_ctx *ctx, const uint8_t *host_rgba, int32_t n, size_t frame_stride);
+/* Uses frames already resident in device memory (no copy; must stay valid until the results were collected). */
+ht_status ht_bind_frames_device(ht_ctx *ctx, const void *dev_rgba, int32_t n, size_t frame_stride);
+
+/* ---- detect: ccv.grayscale + ccv.detect_objects (ccv.js:22-32, 109-246) ---------------------------------- */
+
+/* Enqueues gray -> pyramid -> cascade scan for the bound frames on the stream and returns immediately. */
+ht_status ht_detect_enqueue(ht_ctx *ctx, uint32_t flags);
+/* Waits for the enqueued work, copies the raw hits back, sorted in the reference's emission order
+ * (frame, scale, q, y, x) (ccv.js:154,178,181-182).  counts[f] = hits of frame f (counts may be NULL);
+ * *total = all hits found.  HT_ERR_CAPACITY if total > cap (first cap hits in order are returned). */
+ht_status ht_detect_collect(ht_ctx *ctx, ht_hit *hits, uint32_t cap, uint32_t *counts, uint32_t *total);
+/* Convenience: set geometry if needed + upload + enqueue + collect, for host-resident frames. */
+ht_status ht_detect_batch(ht_ctx *ctx, const uint8_t *host_rgba, int32_t n, int32_t width, int32_t height,
+                          size_t frame_stride, uint32_t flags, ht_hit *hits, uint32_t cap, uint32_t *counts,
+                          uint32_t *total);
+/* Test hook: copies one pyramid plane of one frame back, rows packed (width*height bytes). */
+ht_status ht_pyramid_readback(ht_ctx *ctx, int32_t frame, int32_t level, int32_t slot, uint8_t *out, size_t cap);
+/* Scan statistics of the last collected batch: windows that entered stage j, j = 0..nstages (nstages = survivors). */
+ht_status ht_stage_counts(ht_ctx *ctx, uint64_t *counts, int32_t n);
+
+/* ccv.grayscale drop-in on host RGBA frames, in place (R=G=B=gray, A untouched; ccv.js:22-32). */
+ht_status ht_grayscale_batch(ht_ctx *ctx, uint8_t *host_rgba, int32_t n, int32_t width, int32_t height,
+                             size_t frame_stride);
+/* headtrackr.getWhitebalance (whitebalance.js:5-30) for the bound frames. */
+ht_status ht_whitebalance_batch(ht_ctx *ctx, double *out, int32_t n);
+
+/* ---- host-side post-processing of raw hits (O(n^2) on tens of rects; stays on the CPU by design) ---------- */
+
+/* seq elements from hits (ccv.js:228-233, scale_x by repeated multiplication ccv.js:244-245). */
+ht_status ht_hits_to_rects(const ht_ctx *ctx, const ht_hit *hits, uint32_t n, ht_rect *out);
+/* ccv.array_group + averaging + nested-rect filter (ccv.js:34-107, 249-332). *nout <= n. */
+ht_status ht_group_rects(const ht_rect *seq, uint32_t n, int32_t min_neighbors, ht_rect *out, uint32_t *nout);
+
+/* ---- camshift: camshift.Tracker (camshift.js:148-354), one tracker per stream ----------------------------- */
+
+/* (Re)allocates per-stream tracker state for n streams. */
+ht_status ht_camshift_reserve(ht_ctx *ctx, int32_t nstreams);
+/* initTracker (camshift.js:198-211) for streams [first, first+n) using bound frames [0, n) and one rect each. */
+ht_status ht_camshift_init_batch(ht_ctx *ctx, int32_t first, int32_t n, const ht_cs_rect *rects);
+/* track (camshift.js:213-312) for streams [first, first+n) on bound frames [0, n); out[n] (may be NULL: enqueue only). */
+ht_status ht_camshift_track_batch(ht_ctx *ctx, int32_t first, int32_t n, int32_t calc_angles, ht_cs_trackobj *out);
+
+/* ---- multi-GPU: fixed-size result records, all-gathered over RCCL/xGMI ------------------------------------ */
+
+/* Single-process helper for hosts that drive several GPUs from one process (the Node addon): ctxs[i] are contexts
+ * on distinct devices; records_dev[i] points to nranks*bytes_per_rank bytes of device memory on ctxs[i]'s device
+ * with rank i's own records already at offset i*bytes_per_rank.  Performs one ncclAllGather per rank in a group. */
+ht_status ht_allgather_records(ht_ctx *const *ctxs, int32_t nranks, void *const *records_dev, size_t bytes_per_rank);
+
+/* ---- measurement --------------------------------------------------------------------------------------- */
+
+/* on != 0: bracket every kernel of subsequent ht_detect_* / camshift calls with HIP events on the ctx stream. */
+ht_status ht_profile(ht_ctx *ctx, int32_t on);
+/* Device times accumulated since profiling was switched on (or last reset); *n in: capacity, out: entries. */
+ht_status ht_kernel_times(ht_ctx *ctx, ht_kernel_time *out, int32_t *n, int32_t reset);
+void *ht_stream(const ht_ctx *ctx); /* the hipStream_t the ctx enqueues on */
+ht_status ht_synchronize(ht_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEADTRACKR_HIP_H */

@@ -1,0 +1,174 @@
+"""Parity of the HIP detect path (gray -> pyramid -> cascade scan) with the CPU oracle and the golden vectors.
+Everything goes through the C ABI (headtrackr_amd.api.Context -> libheadtrackr_hip.so).  Bit-exact: bytes, indices
+and the binary64 confidence."""
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from headtrackr_amd import synth
+from headtrackr_amd.api import HT_INPUT_GRAY_IN_R, HT_INPUT_RGBA, HT_SCAN_NO_SPLIT, HT_SCAN_SIMPLE, Context
+from oracle import ht_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+DETECT = load_golden("detect.json")
+CASES = [c for c in DETECT["cases"] if "interval3" not in c["name"]]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context()
+    yield c
+    c.close()
+
+
+def oracle_hits(frame, cascade, frame_index=0, interval=5):
+    h = ho.detect_raw(frame, cascade.blob, interval=interval)
+    out = np.zeros(len(h), dtype=[("frame", "<u4"), ("scale", "<i4"), ("q", "<i4"), ("y", "<i4"), ("x", "<i4"), ("sum", "<f8")])
+    out["frame"] = frame_index
+    for k in ("scale", "q", "x", "y", "sum"):
+        out[k] = h[k]
+    return out
+
+
+def assert_hits_equal(gpu_hits, ref):
+    assert len(gpu_hits) == len(ref), f"{len(gpu_hits)} hits on the GPU, {len(ref)} from the oracle"
+    for k in ("frame", "scale", "q", "y", "x"):
+        assert np.array_equal(gpu_hits[k].astype(np.int64), ref[k].astype(np.int64)), k
+    assert np.array_equal(gpu_hits["sum"].view(np.uint64), ref["sum"].view(np.uint64)), "confidence bits differ"
+
+
+def test_grayscale_exhaustive_2p24(ctx):
+    """every (R,G,B) triple: ccv.js:29 in binary64 + round-half-even, vs the oracle"""
+    v = np.arange(1 << 24, dtype=np.uint32)
+    rgba = np.empty((1, 4096, 4096, 4), dtype=np.uint8)
+    flat = rgba.reshape(-1, 4)
+    flat[:, 0] = v & 0xFF
+    flat[:, 1] = (v >> 8) & 0xFF
+    flat[:, 2] = (v >> 16) & 0xFF
+    flat[:, 3] = (v * 7) & 0xFF  # alpha must be preserved
+    got = ctx.grayscale(rgba)[0]
+    want = ho.grayscale_rgba(rgba[0])
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_golden_case(ctx, case, cascade):
+    """the committed reference-JS vectors: pyramid planes by CRC, raw hits, grouped rects"""
+    w, h = case["w"], case["h"]
+    frame = synth.make(case["gen"], w, h)
+    assert zlib.crc32(frame.tobytes()) == case["input_crc"]
+    hits, counts = ctx.detect_raw(frame)
+    order = [(i, 0) for i in range(1, ctx.num_levels)] + [(i, s) for i in range(12, ctx.num_levels) for s in (1, 2, 3)]
+    assert zlib.crc32(ctx.pyramid_readback(0, 0, 0).tobytes()) == case["gray_crc"]
+    for (i, s), g in zip(order, case["pyramid"]):
+        p = ctx.pyramid_readback(0, i, s)
+        assert (p.shape[1], p.shape[0]) == (g["w"], g["h"])
+        assert zlib.crc32(p.tobytes()) == g["crc"], f"pyramid level {i} slot {s}"
+    rects = ctx.hits_to_rects(hits)
+    assert len(rects) == len(case["raw"])
+    for r, g in zip(rects, case["raw"]):
+        for k in ("x", "y", "width", "height", "confidence"):
+            assert r[k] == g[k], (k, r, g)
+    grouped = ctx.group_rects(rects, case["min_neighbors"])
+    assert len(grouped) == len(case["grouped"])
+    for r, g in zip(grouped, case["grouped"]):
+        for k in ("x", "y", "width", "height", "confidence", "neighbors"):
+            assert r[k] == g[k], (k, r, g)
+    ctx.upload(frame[None])
+    assert ctx.whitebalance()[0] == case["whitebalance"]
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (64, 48), (38, 30), (641, 363)])
+def test_pyramid_planes_vs_oracle(ctx, w, h):
+    frames = np.stack([synth.noise_frame(w, h, 3), synth.smooth_frame(w, h, 4), synth.face_frame(w, h, [(w // 8, h // 8, min(w, h) // 2)])])
+    ctx.set_geometry(w, h, len(frames))
+    ctx.upload(frames)
+    ctx.detect_enqueue(HT_INPUT_RGBA)
+    ctx.detect_collect()
+    for f in range(len(frames)):
+        levels, arena = ho.pyramid(frames[f])
+        assert ctx.num_levels == len(levels)
+        for i, (lw, lh, off) in enumerate(levels):
+            for s in range(4):
+                if off[s] < 0:
+                    continue
+                got = ctx.pyramid_readback(f, i, s)
+                want = ho.plane(levels, arena, i, s)
+                assert got.shape == want.shape and np.array_equal(got, want), f"frame {f} level {i} slot {s}"
+
+
+@pytest.mark.parametrize("mode", [0, HT_SCAN_NO_SPLIT, HT_SCAN_SIMPLE], ids=["split", "nosplit", "simple"])
+def test_mixed_batch_hits_vs_oracle(ctx, cascade, mode):
+    """N / S / F frames in one batch, every scan schedule: raw hits == oracle, in the reference's order"""
+    w, h, n = 320, 240, 12
+    frames = synth.mixed_batch(n, w, h, seed0=1234)
+    hits, counts = ctx.detect_raw(frames, flags=mode)
+    ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(n)])
+    assert_hits_equal(hits, ref)
+    assert int(counts.sum()) == len(ref) and len(ref) > 0
+    # stage survival statistics are part of the measurement contract: compare with the oracle's counters
+    sp = np.zeros(cascade.count + 1, dtype=np.int64)
+    for i in range(n):
+        ho.detect_raw(frames[i], cascade.blob, stage_pass=sp)
+    assert np.array_equal(ctx.stage_counts().astype(np.int64), sp)
+    assert ctx.windows_per_frame * n == sp[0]
+
+
+def test_gray_in_r_entry(ctx, cascade):
+    """HT_INPUT_GRAY_IN_R == calling ccv.detect_objects on an already gray canvas"""
+    frame = synth.face_frame(320, 240, [(100, 60, 96)])
+    gray = ho.grayscale_rgba(frame)
+    a, _ = ctx.detect_raw(frame, flags=HT_INPUT_RGBA)
+    b, _ = ctx.detect_raw(gray, flags=HT_INPUT_GRAY_IN_R)
+    assert len(a) == 9 and a.tobytes() == b.tobytes()
+
+
+def test_720p_vs_oracle(ctx, cascade):
+    w, h = 1280, 720
+    frames = np.stack([synth.smooth_frame(w, h, 77), synth.face_frame(w, h, [(400, 200, 240), (900, 100, 64), (100, 500, 150)])])
+    hits, counts = ctx.detect_raw(frames)
+    ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(2)])
+    assert_hits_equal(hits, ref)
+    assert ctx.windows_per_frame == 1007428
+
+
+def test_full_batch_is_frame_independent(ctx, cascade):
+    """C2 size (256 x 320x240): every frame's hits equal those of the same frame detected alone (size-independent
+    property; the oracle checks a sample)"""
+    w, h, n = 320, 240, 256
+    frames = synth.mixed_batch(n, w, h, seed0=1234)
+    hits, counts = ctx.detect_raw(frames)
+    assert len(counts) == n
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    for i in (0, 1, 2, 17, 128, 255):
+        alone, _ = ctx.detect_raw(frames[i])
+        got = hits[starts[i] : starts[i + 1]].copy()
+        got["frame"] = 0
+        assert got.tobytes() == alone.tobytes()
+        assert_hits_equal(alone, oracle_hits(frames[i], cascade, 0))
+    # frames of family F must have produced detections, N must not
+    assert all(counts[i] == 0 for i in range(0, n, 3))
+    assert sum(int(counts[i] > 0) for i in range(2, n, 3)) > n // 3 * 0.9
+
+
+def test_tiny_hit_capacity_reports_overflow(cascade):
+    from headtrackr_amd.api import HtError
+
+    c = Context(hit_capacity=4)
+    with pytest.raises(HtError) as e:
+        c.detect_raw(synth.face_frame(320, 240, [(100, 60, 96)]))
+    assert e.value.status == -4
+    c.close()
+
+
+def test_queue_overflow_falls_back_inline(cascade):
+    """a survivor queue that is far too small: the tile kernel must finish the overflow itself, results unchanged"""
+    c = Context(queue_capacity=8)
+    frames = synth.mixed_batch(6, 320, 240, seed0=1234)
+    hits, _ = c.detect_raw(frames)
+    ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(6)])
+    assert_hits_equal(hits, ref)
+    c.close()

@@ -101,7 +101,7 @@ def main():
         hits, counts = ctx.detect_collect(cap=1 << 18)
         if a.workload == "c3":
             # detect once, then 60 camshift track() calls on the (static) batch, SURVEY.md §8 C3
-            starts = np.concatenate([[0], np.cumsum(counts)])
+            starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
             rects = []
             for f in range(nf):
                 if counts[f]:

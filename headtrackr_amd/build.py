@@ -21,7 +21,7 @@ HIP_SOURCES = ["ht_context.hip", "ht_pyramid.hip", "ht_scan.hip", "ht_camshift.h
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIP_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
-    "-fgpu-rdc" if False else "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+    "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC,
 ]
 
@@ -35,7 +35,7 @@ def _newer(target: str, deps) -> bool:
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ht_internal.h"), os.path.join(ROOT, "include", "headtrackr_hip.h"), os.path.abspath(__file__)]
+    deps = srcs + [os.path.join(CSRC, "ht_internal.h"), os.path.join(CSRC, "ht_cascade_gen.inc"), os.path.join(ROOT, "include", "headtrackr_hip.h"), os.path.abspath(__file__)]
     if force or _newer(LIB, deps):
         objs = []
         for s in srcs:
@@ -46,7 +46,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
                     print(" ".join(cmd))
                 subprocess.check_call(cmd)
             objs.append(o)
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

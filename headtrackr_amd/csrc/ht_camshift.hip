@@ -1,7 +1,359 @@
-// ht_camshift.hip — camshift.Tracker on the device (placeholder until the kernels land).
+// ht_camshift.hip — camshift.Tracker on the device (reference: /root/reference/src/camshift.js).
+//
+//   Histogram            camshift.js:49-72     bins[256*(R>>4) + 16*(G>>4) + (B>>4)]++ over RGBA pixels
+//   initTracker          camshift.js:198-211   model histogram of the tracked rect (outside the canvas = transparent
+//                                              black = bin 0), search window = rect
+//   track -> camShift    camshift.js:213-259   size / angle from second moments, new window = 1.1 x object size
+//   meanShift            camshift.js:261-312   full-frame histogram, weights, <= 10 window iterations
+//   getWeights           camshift.js:314-330   w = ch ? min(mh/ch, 1) : 0
+//   Moments              camshift.js:79-120
+//
+// Device mapping: one tracker ("stream") per frame of the bound batch; state (model histogram, search window, track
+// object) stays in HBM between calls.  track = (1) k_cs_hist: LDS-privatised 4096-bin histogram per frame chunk,
+// merged with global atomics; (2) k_cs_meanshift: ONE workgroup per stream keeps the 4096-entry weight LUT in LDS
+// (binary64, 32 KB) and runs the whole <=10-iteration mean-shift loop: each iteration is a window moment reduction
+// straight from the RGBA pixels through the LUT — the back-projection image of the reference (camshift.js:332-353) is
+// never materialised, it is only observable through debug getters.  Moment sums are binary64 with a fixed
+// thread-to-pixel assignment and a fixed reduction tree (deterministic); the summation ORDER differs from the
+// reference's column-major scalar loop, so results are equal up to rounding in the last bits of xc/yc — the
+// acceptance bound of BASELINE.json (+-1 px, +-0.5 deg) covers the rare truncation flips this can cause.
+#include <cmath>
+#include <map>
+#include <vector>
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: librccl.so is opened lazily (dlopen) the first time ht_allgather_records runs
+
 #include "ht_internal.h"
 
-extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t) { return ht_fail(c, HT_ERR_STATE, "camshift: not built yet"); }
-extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t, int32_t, const ht_cs_rect *) { return ht_fail(c, HT_ERR_STATE, "camshift: not built yet"); }
-extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t, int32_t, int32_t, ht_cs_trackobj *) { return ht_fail(c, HT_ERR_STATE, "camshift: not built yet"); }
-extern "C" ht_status ht_allgather_records(ht_ctx *const *, int32_t, void *const *, size_t) { return HT_ERR_STATE; }
+namespace {
+
+constexpr int CS_NT = 512;          // threads of the mean-shift workgroup
+constexpr int HIST_NT = 256;
+constexpr int HIST_PIX_PER_WG = 16384;
+
+__device__ __forceinline__ uint32_t cs_bin(uint32_t px) {  // camshift.js:63-66 (px = R | G<<8 | B<<16 | A<<24)
+    return ((px & 0xf0u) << 4) | ((px >> 8) & 0xf0u) | ((px >> 20) & 0xfu);
+}
+
+__device__ __forceinline__ int32_t toint32(double v) {  // ECMAScript ToInt32 (>>0, <<2)
+    if (!(fabs(v) < 1.0e300)) return 0;                  // NaN, +-Infinity
+    const double t = trunc(v);
+    if (fabs(t) < 2147483648.0) return (int32_t)t;
+    double m = fmod(t, 4294967296.0);
+    if (m < 0) m += 4294967296.0;
+    return (int32_t)(uint32_t)m;
+}
+
+// initTracker: one workgroup per stream
+__global__ __launch_bounds__(256) void k_cs_init(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H,
+                                                 const ht_cs_rect *__restrict__ rects, HtCsState *__restrict__ states, int first) {
+    __shared__ uint32_t h[4096];
+    const int s = blockIdx.x;
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const ht_cs_rect r = rects[s];
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)s * frame_stride);
+    const long long n = (long long)max(r.width, 0) * (long long)max(r.height, 0);
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = r.y + (int)(i / r.width), x = r.x + (int)(i % r.width);
+        uint32_t b = 0;  // getImageData outside the canvas: transparent black -> bin 0 (camshift.js:206)
+        if (x >= 0 && x < W && y >= 0 && y < H) b = cs_bin(img[(size_t)y * W + x]);
+        atomicAdd(&h[b], 1u);
+    }
+    __syncthreads();
+    HtCsState &st = states[first + s];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) st.model[i] = h[i];
+    if (threadIdx.x == 0) {
+        st.sw[0] = r.x, st.sw[1] = r.y, st.sw[2] = r.width, st.sw[3] = r.height;  // camshift.js:209
+        st.x = st.y = st.width = st.height = st.angle = 0.0;                         // camshift.js:210
+    }
+}
+
+// full-frame histogram (camshift.js:268): grid (chunks, streams); hist[stream][4096] zeroed by the host
+__global__ __launch_bounds__(HIST_NT) void k_cs_hist(const uint8_t *__restrict__ frames, size_t frame_stride, uint32_t npix,
+                                                     uint32_t *__restrict__ hist) {
+    __shared__ uint32_t h[4096];
+    for (int i = threadIdx.x; i < 4096; i += HIST_NT) h[i] = 0;
+    __syncthreads();
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)blockIdx.y * frame_stride);
+    const uint32_t beg = blockIdx.x * HIST_PIX_PER_WG, end = min(beg + HIST_PIX_PER_WG, npix);
+    for (uint32_t i = beg + threadIdx.x; i < end; i += HIST_NT) atomicAdd(&h[cs_bin(img[i])], 1u);
+    __syncthreads();
+    uint32_t *out = hist + (size_t)blockIdx.y * 4096;
+    for (int i = threadIdx.x; i < 4096; i += HIST_NT) {
+        const uint32_t v = h[i];
+        if (v) atomicAdd(&out[i], v);
+    }
+}
+
+struct Mom {
+    double m00, m10, m01, m11, m20, m02;
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// camshift.Moments (camshift.js:79-120) over columns [x, w) x rows [y, h) — w, h are the right / bottom EDGES
+template <bool SECOND>
+__device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, int W, const double *lut, int x, int y, int w, int h,
+                                              double (*red)[CS_NT / 64]) {
+    Mom m = {0, 0, 0, 0, 0, 0};
+    const int ww = w - x, hh = h - y;
+    if (ww > 0 && hh > 0) {
+        const int n = ww * hh;
+        for (int i = threadIdx.x; i < n; i += CS_NT) {
+            const int j = i / ww, c = i - j * ww;  // row-major walk: coalesced RGBA reads
+            const double val = lut[cs_bin(img[(size_t)(y + j) * W + (x + c)])];
+            const double vx = (double)c, vy = (double)j;
+            m.m00 += val;
+            m.m01 += vy * val;
+            m.m10 += vx * val;
+            if (SECOND) {
+                m.m11 += vx * vy * val;
+                m.m02 += vy * vy * val;
+                m.m20 += vx * vx * val;
+            }
+        }
+    }
+    double v[6] = {m.m00, m.m10, m.m01, m.m11, m.m20, m.m02};
+    const int nv = SECOND ? 6 : 3;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();  // red[] may still be read from the previous call
+    for (int k = 0; k < nv; k++) {
+        const double s = wave_sum_f64(v[k]);
+        if (lane == 0) red[k][wave] = s;
+    }
+    __syncthreads();
+    for (int k = 0; k < nv; k++) {
+        double s = 0.0;
+        for (int q = 0; q < CS_NT / 64; q++) s += red[k][q];  // fixed order
+        v[k] = s;
+    }
+    m.m00 = v[0], m.m10 = v[1], m.m01 = v[2], m.m11 = v[3], m.m20 = v[4], m.m02 = v[5];
+    return m;
+}
+
+__global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H,
+                                                        const uint32_t *__restrict__ hist, HtCsState *__restrict__ states, int first,
+                                                        int calc_angles, ht_cs_trackobj *__restrict__ out) {
+    __shared__ double lut[4096];
+    __shared__ double red[6][CS_NT / 64];
+    __shared__ int s_sw[4];
+    const int s = blockIdx.x;
+    HtCsState &st = states[first + s];
+    const uint32_t *cur = hist + (size_t)s * 4096;
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)s * frame_stride);
+    for (int i = threadIdx.x; i < 4096; i += CS_NT) {  // getWeights, camshift.js:314-330
+        const uint32_t ch = cur[i];
+        double p = 0.0;
+        if (ch != 0) {
+            p = (double)st.model[i] / (double)ch;
+            p = p < 1.0 ? p : 1.0;
+        }
+        lut[i] = p;
+    }
+    if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
+    __syncthreads();
+    int swx = s_sw[0], swy = s_sw[1];
+    const int sww = s_sw[2], swh = s_sw[3];
+    int prevx = swx, prevy = swy;  // camshift.js:280-281
+    Mom m = {0, 0, 0, 0, 0, 0};
+    bool have_second = false;
+    int wadx = 0, wady = 0, wadw = 0, wadh = 0;
+    for (int it = 0; it < 10; it++) {  // camshift.js:284-306 (every thread runs the identical scalar logic)
+        wadx = max(swx, 0);
+        wady = max(swy, 0);
+        wadw = min(wadx + sww, W);
+        wadh = min(wady + swh, H);
+        if (it == 9) {
+            m = window_moments<true>(img, W, lut, wadx, wady, wadw, wadh, red);
+            have_second = true;
+        } else {
+            m = window_moments<false>(img, W, lut, wadx, wady, wadw, wadh, red);
+        }
+        const double inv = 1.0 / m.m00, xc = m.m10 * inv, yc = m.m01 * inv;  // camshift.js:109-111
+        swx += toint32(xc - (double)sww / 2);                                    // camshift.js:295
+        swy += toint32(yc - (double)swh / 2);                                    // camshift.js:296
+        if (swx == prevx && swy == prevy) {                                      // camshift.js:299-301
+            if (!have_second) m = window_moments<true>(img, W, lut, wadx, wady, wadw, wadh, red);
+            have_second = true;
+            break;
+        }
+        prevx = swx;
+        prevy = swy;
+    }
+    if (threadIdx.x != 0) return;
+    swx = max(0, min(swx, W));  // camshift.js:308-309
+    swy = max(0, min(swy, H));
+    const double invM00 = 1.0 / m.m00, xc = m.m10 * invM00, yc = m.m01 * invM00;
+    const double mu20 = m.m20 - m.m10 * xc, mu02 = m.m02 - m.m01 * yc, mu11 = m.m11 - m.m01 * xc;  // camshift.js:116-118
+    const double a = mu20 * invM00, c = mu02 * invM00;  // camshift.js:230-231
+    double width, height, angle;
+    if (calc_angles) {  // camshift.js:233-245
+        const double b = mu11 * invM00, d = a + c;
+        const double e = sqrt((4 * b * b) + ((a - c) * (a - c)));
+        width = (double)(int32_t)((uint32_t)toint32(sqrt((d - e) * 0.5)) << 2);
+        height = (double)(int32_t)((uint32_t)toint32(sqrt((d + e) * 0.5)) << 2);
+        angle = atan2(2 * b, a - c + e);
+        if (angle < 0) angle = angle + 3.141592653589793;
+    } else {  // camshift.js:247-249
+        width = (double)(int32_t)((uint32_t)toint32(sqrt(a)) << 2);
+        height = (double)(int32_t)((uint32_t)toint32(sqrt(c)) << 2);
+        angle = 3.141592653589793 / 2;
+    }
+    double cx = (double)swx + (double)sww / 2, cy = (double)swy + (double)swh / 2;  // camshift.js:253-254 (old window size)
+    cx = cx < (double)W ? cx : (double)W;
+    cy = cy < (double)H ? cy : (double)H;
+    const double tx = floor(cx > 0 ? cx : 0.0), ty = floor(cy > 0 ? cy : 0.0);
+    const int nsww = (int)floor(1.1 * width), nswh = (int)floor(1.1 * height);  // camshift.js:257-258
+    st.sw[0] = swx, st.sw[1] = swy, st.sw[2] = nsww, st.sw[3] = nswh;
+    st.x = tx, st.y = ty, st.width = width, st.height = height, st.angle = angle;
+    if (out) {
+        ht_cs_trackobj o;
+        o.x = tx, o.y = ty, o.width = width, o.height = height, o.angle = angle;
+        o.sw_x = swx, o.sw_y = swy, o.sw_width = nsww, o.sw_height = nswh;
+        out[s] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
+    if (!c || nstreams <= 0) return HT_ERR_INVALID;
+    HT_HIP(c, hipSetDevice(c->device));
+    if (c->cs_streams >= nstreams) return HT_OK;
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    HtCsState *ns = nullptr;
+    if (hipMalloc(&ns, sizeof(HtCsState) * (size_t)nstreams) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_reserve: hipMalloc failed");
+    HT_HIP(c, hipMemset(ns, 0, sizeof(HtCsState) * (size_t)nstreams));
+    if (c->d_cs) {  // keep existing trackers
+        HT_HIP(c, hipMemcpy(ns, c->d_cs, sizeof(HtCsState) * (size_t)c->cs_streams, hipMemcpyDeviceToDevice));
+        (void)hipFree(c->d_cs);
+    }
+    c->d_cs = ns;
+    if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
+    if (c->d_cs_out) (void)hipFree(c->d_cs_out);
+    c->d_cs_hist = nullptr;
+    c->d_cs_out = nullptr;
+    HT_HIP(c, hipMalloc(&c->d_cs_hist, sizeof(uint32_t) * 4096 * (size_t)nstreams));
+    HT_HIP(c, hipMalloc(&c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)nstreams));
+    c->cs_streams = nstreams;
+    return HT_OK;
+}
+
+extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n, const ht_cs_rect *rects) {
+    if (!c || !rects) return HT_ERR_INVALID;
+    if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_camshift_init_batch: bind n frames first");
+    if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_init_batch: stream range not reserved");
+    HT_HIP(c, hipSetDevice(c->device));
+    ht_cs_rect *d_rects = reinterpret_cast<ht_cs_rect *>(c->d_cs_out);  // scratch: sizeof(ht_cs_trackobj) >= sizeof(ht_cs_rect)
+    HT_HIP(c, hipMemcpyAsync(d_rects, rects, sizeof(ht_cs_rect) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    {
+        HtProfScope ps(c, "cs_init");
+        hipLaunchKernelGGL(k_cs_init, dim3(n), dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, d_rects, c->d_cs, first);
+        HT_HIP(c, hipGetLastError());
+    }
+    HT_HIP(c, hipStreamSynchronize(c->stream));  // rects[] is the caller's (pageable) memory
+    return HT_OK;
+}
+
+extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n, int32_t calc_angles, ht_cs_trackobj *out) {
+    if (!c) return HT_ERR_INVALID;
+    if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_batch: bind n frames first");
+    if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_track_batch: stream range not reserved");
+    if (c->W == 0 || c->H == 0) return HT_OK;  // camshift.js:219
+    HT_HIP(c, hipSetDevice(c->device));
+    const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
+    HT_HIP(c, hipMemsetAsync(c->d_cs_hist, 0, sizeof(uint32_t) * 4096 * (size_t)n, c->stream));
+    {
+        HtProfScope ps(c, "cs_hist");
+        hipLaunchKernelGGL(k_cs_hist, dim3((npix + HIST_PIX_PER_WG - 1) / HIST_PIX_PER_WG, n), dim3(HIST_NT), 0, c->stream, c->d_frames,
+                           c->frame_stride, npix, c->d_cs_hist);
+        HT_HIP(c, hipGetLastError());
+    }
+    {
+        HtProfScope ps(c, "cs_meanshift");
+        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, c->d_cs_hist, c->d_cs,
+                           first, calc_angles, c->d_cs_out);
+        HT_HIP(c, hipGetLastError());
+    }
+    if (out) {
+        HT_HIP(c, hipMemcpyAsync(out, c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return HT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// multi-GPU: in-place all-gather of fixed-size records over RCCL (xGMI), single-process form for the Node host.
+// (bench.py / torch.distributed use one process per GPU and call RCCL through torch instead.)
+
+namespace {
+struct CommSet {
+    std::vector<int> devs;
+    std::vector<ncclComm_t> comms;
+};
+std::map<std::vector<int>, CommSet> g_comms;
+
+struct Rccl {
+    void *h = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl &rccl() {
+    static Rccl r;
+    if (r.h) return r;
+    r.h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.h) r.h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!r.h) return r;
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(r.h, "ncclCommInitAll"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.h, "ncclGroupEnd"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.h, "ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.h, "ncclGetErrorString"));
+    r.ok = r.CommInitAll && r.GroupStart && r.GroupEnd && r.AllGather && r.GetErrorString;
+    return r;
+}
+}  // namespace
+
+extern "C" ht_status ht_allgather_records(ht_ctx *const *ctxs, int32_t nranks, void *const *records_dev, size_t bytes_per_rank) {
+    if (!ctxs || !records_dev || nranks <= 0 || bytes_per_rank == 0) return HT_ERR_INVALID;
+    if (nranks == 1) return HT_OK;
+    std::vector<int> devs(nranks);
+    for (int i = 0; i < nranks; i++) {
+        if (!ctxs[i] || !records_dev[i]) return HT_ERR_INVALID;
+        devs[i] = ctxs[i]->device;
+    }
+    Rccl &R = rccl();
+    if (!R.ok) return ht_fail(ctxs[0], HT_ERR_HIP, "ht_allgather_records: librccl.so could not be loaded");
+    auto it = g_comms.find(devs);
+    if (it == g_comms.end()) {
+        CommSet cs;
+        cs.devs = devs;
+        cs.comms.resize(nranks);
+        if (R.CommInitAll(cs.comms.data(), nranks, devs.data()) != ncclSuccess)
+            return ht_fail(ctxs[0], HT_ERR_HIP, "ht_allgather_records: ncclCommInitAll failed");
+        it = g_comms.emplace(devs, cs).first;
+    }
+    ncclResult_t r = R.GroupStart();
+    for (int i = 0; i < nranks && r == ncclSuccess; i++) {
+        char *buf = static_cast<char *>(records_dev[i]);
+        r = R.AllGather(buf + (size_t)i * bytes_per_rank, buf, bytes_per_rank, ncclChar, it->second.comms[i], ctxs[i]->stream);
+    }
+    if (r == ncclSuccess) r = R.GroupEnd();
+    if (r != ncclSuccess) return ht_fail(ctxs[0], HT_ERR_HIP, std::string("ht_allgather_records: ") + R.GetErrorString(r));
+    for (int i = 0; i < nranks; i++) {
+        HT_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
+        HT_HIP(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+    }
+    return HT_OK;
+}

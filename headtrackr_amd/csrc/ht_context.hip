@@ -213,6 +213,7 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         c->own_stream = true;
     }
     c->split_stage = std::min<uint32_t>(4, c->nstages);
+    c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     if ((st = upload_cascade(c)) != HT_OK) return bail(st);
     if (hipMalloc(&c->d_counters, sizeof(HtCounters)) != hipSuccess ||
         hipMalloc(&c->d_hits, (size_t)c->hit_capacity * sizeof(ht_hit)) != hipSuccess) {
@@ -243,6 +244,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     free_geometry(c);
     if (c->d_tile_feats) (void)hipFree(c->d_tile_feats);
     if (c->d_deep_feats) (void)hipFree(c->d_deep_feats);
+    if (c->d_patch_feats) (void)hipFree(c->d_patch_feats);
     if (c->d_stages) (void)hipFree(c->d_stages);
     if (c->d_frames_own) (void)hipFree(c->d_frames_own);
     if (c->d_hits) (void)hipFree(c->d_hits);

@@ -48,6 +48,15 @@ struct alignas(16) HtDeepFeature {
 };
 static_assert(sizeof(HtDeepFeature) == 80, "HtDeepFeature");
 
+// Deep kernel: offsets into the per-wavefront window patch in LDS (24x24 + 12x12 + 6x6 bytes, see ht_scan.hip).
+struct alignas(16) HtPatchFeature {
+    uint16_t poff[HT_MAXPTS];  // slots >= np repeat slot 0
+    uint16_t noff[HT_MAXPTS];
+    int64_t a0i, a1i;          // alpha * 1e8 as exact integers
+    double a0, a1;
+};
+static_assert(sizeof(HtPatchFeature) == 64, "HtPatchFeature");
+
 struct HtDevStage {
     uint32_t first, count;
     uint32_t maxpts;  // max(np, nn) over the stage's features
@@ -134,6 +143,9 @@ struct ht_ctx {
     std::vector<HtBlobFeature> h_feats;
     HtTileFeature *d_tile_feats = nullptr;
     HtDeepFeature *d_deep_feats = nullptr;
+    HtPatchFeature *d_patch_feats = nullptr;
+    bool builtin_cascade = false;  // blob == the cascade ht_cascade_gen.inc was generated from
+    uint32_t deep_bias = 3;        // tile kernel hands survivors to the deep kernel when n*bias*ceil(count/64) <= count
     HtDevStage *d_stages = nullptr;
     uint32_t split_stage = 4;  // stages [0, split) in the tile kernel, [split, nstages) in the deep kernel
 
@@ -203,6 +215,7 @@ struct HtProfScope {
 ht_status ht_launch_pyramid(ht_ctx *ctx, uint32_t flags);   // ht_pyramid.hip
 ht_status ht_launch_scan(ht_ctx *ctx, uint32_t flags);      // ht_scan.hip
 ht_status ht_scan_tile_tables(ht_ctx *ctx);                 // ht_scan.hip: LDS-offset feature table
-ht_status ht_scan_plan_tiles(ht_ctx *ctx);                  // ht_scan.hip: per-scale tiling for the geometry
+ht_status ht_scan_plan_tiles(ht_ctx *ctx);
+bool ht_scan_is_builtin_cascade(const uint8_t *blob, size_t len);  // ht_scan.hip                  // ht_scan.hip: per-scale tiling for the geometry
 ht_status ht_launch_gray_inplace(ht_ctx *ctx, uint8_t *d_rgba, int n, size_t stride);  // ht_pyramid.hip
 ht_status ht_launch_whitebalance(ht_ctx *ctx, double *d_out);                            // ht_pyramid.hip

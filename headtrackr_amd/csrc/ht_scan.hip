@@ -23,6 +23,7 @@
 //     reported confidence of full survivors.
 //   * k_scan_simple — one thread per window straight from HBM; slow, kept as an independent cross-check.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 
 #include "ht_internal.h"
@@ -42,6 +43,13 @@ constexpr int P12_BASE = P0_BYTES;
 constexpr int LDS_TILE_BYTES = P0_BYTES + GH * G_PITCH;  // 26144
 constexpr int MAXWIN = TXH * TYH;            // 2048 windows per tile
 static_assert(PITCH0 % 4 == 0 && P0_BYTES % 4 == 0, "alignment");
+
+// unified-base LDS offsets of a feature point (x, y) on plane 0 / 1 / 2, relative to the window base B
+#define HT_O0(x, y) ((y) * PITCH0 + (x))                      // level i:        1 B/px, row pitch P
+#define HT_O1(x, y) (P12_BASE + (y) * G_PITCH + 2 * (x))      // level i+6:      2 B/px, row pitch 2P
+#define HT_O2(x, y) (P12_BASE + 1 + 4 * (y) * PITCH0 + 4 * (x))  // level i+12 q: odd bytes, 4 B/px, row pitch 4P
+
+#include "ht_cascade_gen.inc"  // straight-line code for the first HT_GEN_STAGES stages of the built-in cascade
 
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
@@ -104,10 +112,11 @@ __device__ __forceinline__ double eval_stage_lds(const uint8_t *lds, uint32_t B,
     return sum;
 }
 
-__global__ __launch_bounds__(NT) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+template <bool GEN>
+__global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                    const HtDevLevel *__restrict__ levels, const HtScanScale *__restrict__ scales,
                                                    int nscales, const HtTileFeature *__restrict__ feats,
-                                                   const HtDevStage *__restrict__ stages, int nstages, int split,
+                                                   const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,
                                                    uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
                                                    uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
                                                    HtCounters *__restrict__ ctr) {
@@ -172,7 +181,10 @@ __global__ __launch_bounds__(NT) void k_scan_tiles(const uint8_t *__restrict__ a
     int cur = 0;
     bool pushed = (split >= nstages);
     for (int s = 0; s < nstages; s++) {
-        if (s == split && !pushed) {
+        const HtDevStage st = stages[s];
+        // hand-off rule: from stage `split` on, survivors leave for k_scan_deep (one wavefront per window, features
+        // across lanes) as soon as that is cheaper than keeping them on a few lanes of this workgroup
+        if (s >= split && !pushed && n_in * deep_bias * ((st.count + 63u) >> 6) <= st.count) {
             // hand the survivors of the first `split` stages to k_scan_deep through the global queue
             pushed = true;
             if (tid == 0) s_qbase = atomicAdd(&ctr->nqueue, n_in);
@@ -190,7 +202,7 @@ __global__ __launch_bounds__(NT) void k_scan_tiles(const uint8_t *__restrict__ a
                 e.y = (uint16_t)(ay >> 1);
                 e.scale = (uint8_t)S.l0;
                 e.q = (uint8_t)(((ay & 1u) << 1) | (ax & 1u));
-                e.pad = 0;
+                e.pad = (uint16_t)s;  // first stage the deep kernel has to run
                 e.pad2 = 0;
                 queue[qb + i] = e;
             }
@@ -199,7 +211,6 @@ __global__ __launch_bounds__(NT) void k_scan_tiles(const uint8_t *__restrict__ a
             qoff += npush;  // queue full: finish the remaining survivors right here
             n_in -= npush;
         }
-        const HtDevStage st = stages[s];
         const HtTileFeature *F = feats + st.first;
         const bool last = (s == nstages - 1);
         uint32_t n_valid = 0;
@@ -211,8 +222,18 @@ __global__ __launch_bounds__(NT) void k_scan_tiles(const uint8_t *__restrict__ a
             const uint32_t yy = (id * S.div_magic) >> 20, xx = id - yy * (uint32_t)S.tw2;
             valid = valid && xx < (uint32_t)tw;
             const uint32_t B = 2u * (yy * PITCH0 + xx);
-            const double sum = eval_stage_lds(lds, valid ? B : 0u, F, st.count);
-            const bool pass = valid && !(sum < st.threshold);  // ccv.js:222
+            double sum = 0.0;
+            bool pass;
+            if (GEN && s < HT_GEN_STAGES) {
+                // generated straight-line stage: exact integer decision (see tools/gen_cascade_code.py)
+                const uint32_t Fv = ht_gen_stage(s, lds + (valid ? B : 0u));
+                pass = valid && Fv >= HT_GEN_FMIN[s];
+                if (valid && Fv == HT_GEN_FTIE[s])  // exact tie with the threshold: let the sequential binary64 sum decide
+                    pass = !(eval_stage_lds(lds, B, F, st.count) < st.threshold);
+            } else {
+                sum = eval_stage_lds(lds, valid ? B : 0u, F, st.count);
+                pass = valid && !(sum < st.threshold);  // ccv.js:222
+            }
             const unsigned long long m = __ballot(pass);
             if (s == 0) n_valid += __popcll(__ballot(valid));
             if (m) {
@@ -305,49 +326,88 @@ __device__ __forceinline__ long long wave_sum_i64(long long v) {
     return v;
 }
 
+// ---- deep kernel ------------------------------------------------------------------------------------------------
+// Per-wavefront window patch in LDS: the 24x24 window of level i, its 12x12 counterpart on level i+6 and the 6x6 one on
+// variant q of level i+12 = 756 bytes, loaded once per window; every later stage reads pixels from there.
+constexpr int PATCH1 = 576, PATCH2 = 720, PATCH_BYTES = 768;
+constexpr int DEEP_WAVES = 4;  // waves per workgroup
+
+__device__ __forceinline__ bool patch_fire(const uint8_t *patch, const HtPatchFeature *__restrict__ fp, uint32_t maxpts) {
+    const uint4 P = *reinterpret_cast<const uint4 *>(fp->poff);  // 8 x u16
+    const uint4 N = *reinterpret_cast<const uint4 *>(fp->noff);
+    const uint32_t pw[4] = {P.x, P.y, P.z, P.w}, nw[4] = {N.x, N.y, N.z, N.w};
+    uint32_t pmin = 255u, nmax = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < HT_MAXPTS; j++) {
+        if (j < maxpts) {  // maxpts is wave-uniform; slots >= np/nn repeat slot 0
+            const uint32_t po = (j & 1) ? (pw[j >> 1] >> 16) : (pw[j >> 1] & 0xffffu);
+            const uint32_t no = (j & 1) ? (nw[j >> 1] >> 16) : (nw[j >> 1] & 0xffffu);
+            pmin = min(pmin, (uint32_t)patch[po]);
+            nmax = max(nmax, (uint32_t)patch[no]);
+        }
+    }
+    return pmin > nmax;
+}
+
 // sequential binary64 stage sum in the reference's order: fire bits in parallel, adds in order (all lanes redundantly)
-__device__ __forceinline__ double deep_stage_sum_exact(const HtDeepFeature *__restrict__ F, uint32_t count, uint32_t maxpts,
-                                                       HT_WIN_ARGS, uint32_t lane) {
+__device__ __forceinline__ double patch_stage_sum_exact(const uint8_t *patch, const HtPatchFeature *__restrict__ F, uint32_t count,
+                                                        uint32_t maxpts, uint32_t lane) {
     double sum = 0.0;
     for (uint32_t kb = 0; kb < count; kb += 64) {
         const uint32_t k = kb + lane;
         bool fire = false;
-        if (k < count) fire = deep_fire(&F[k], HT_WIN_PASS, maxpts);
+        if (k < count) fire = patch_fire(patch, &F[k], maxpts);
         const unsigned long long m = __ballot(fire);
         const uint32_t nn = min(64u, count - kb);
         for (uint32_t t = 0; t < nn; t++) {
-            const HtDeepFeature &f = F[kb + t];
-            sum = __dadd_rn(sum, ((m >> t) & 1ull) ? f.a1 : f.a0);
+            const uint4 A = *reinterpret_cast<const uint4 *>(&F[kb + t].a0);  // uniform: scalar load of {a0, a1}
+            const bool f1 = (m >> t) & 1ull;
+            sum = __dadd_rn(sum, __hiloint2double((int)(f1 ? A.w : A.y), (int)(f1 ? A.z : A.x)));
         }
     }
     return sum;
 }
 
-__global__ __launch_bounds__(256) void k_scan_deep(const uint8_t *__restrict__ arena, uint64_t arena_stride,
-                                                   const HtDevLevel *__restrict__ levels, int next,
-                                                   const HtDeepFeature *__restrict__ feats, const HtDevStage *__restrict__ stages,
-                                                   int nstages, int split, int use_int, const HtQueueEntry *__restrict__ queue,
-                                                   uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
-                                                   HtCounters *__restrict__ ctr) {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+__global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+                                                               const HtDevLevel *__restrict__ levels, int next,
+                                                               const HtPatchFeature *__restrict__ feats,
+                                                               const HtDevStage *__restrict__ stages, int nstages, int use_int,
+                                                               const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
+                                                               ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DEEP_WAVES][PATCH_BYTES];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint8_t *patch = s_patch[wv];
+    const uint32_t wave = blockIdx.x * DEEP_WAVES + wv, nwaves = gridDim.x * DEEP_WAVES;
     const uint32_t n = min(ctr->nqueue, queue_cap);
     for (uint32_t e = wave; e < n; e += nwaves) {
         const HtQueueEntry ent = queue[e];
-        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x, (uint32_t)ent.y)
+        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
+                     (uint32_t)ent.y)
+        // load the patch (wave-private: no workgroup barrier needed, LDS ops of one wave complete in order)
+        for (uint32_t i = lane; i < 288; i += 64) {  // plane 0: 24 rows x 12 u16 (window origin is 2-byte aligned)
+            const uint32_t r = i / 12, c2 = (i - r * 12) * 2;
+            *reinterpret_cast<uint16_t *>(&patch[r * 24 + c2]) = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);
+        }
+        for (uint32_t i = lane; i < 144; i += 64) {  // plane 1: 12 x 12 bytes
+            const uint32_t r = i / 12, c = i - r * 12;
+            patch[PATCH1 + i] = fb[o1 + r * (uint32_t)s1 + c];
+        }
+        if (lane < 36) {  // plane 2: 6 x 6 bytes
+            const uint32_t r = lane / 6, c = lane - r * 6;
+            patch[PATCH2 + lane] = fb[o2 + r * (uint32_t)s2 + c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         bool alive = true;
         double conf = 0.0;
-        for (int j = split; j < nstages; j++) {
+        for (int j = (int)ent.pad; j < nstages; j++) {
             const HtDevStage st = stages[j];
-            const HtDeepFeature *F = feats + st.first;
+            const HtPatchFeature *F = feats + st.first;
             if (lane == 0) atomicAdd(&ctr->stage_in[j], 1ull);
             bool need_exact = true;
             if (use_int) {
                 long long acc = 0;
-                for (uint32_t k = lane; k < st.count; k += 64) {
-                    const HtDeepFeature &f = F[k];
-                    acc += deep_fire(&f, HT_WIN_PASS, st.maxpts) ? f.a1i : f.a0i;
-                }
+                for (uint32_t k = lane; k < st.count; k += 64) acc += patch_fire(patch, &F[k], st.maxpts) ? F[k].a1i : F[k].a0i;
                 const long long Ssum = wave_sum_i64(acc);
                 if (Ssum < st.thri) {  // sum < threshold decided exactly, independent of summation order
                     alive = false;
@@ -356,7 +416,7 @@ __global__ __launch_bounds__(256) void k_scan_deep(const uint8_t *__restrict__ a
                 need_exact = (Ssum == st.thri) || (j == nstages - 1);
             }
             if (need_exact) {
-                const double sum = deep_stage_sum_exact(F, st.count, st.maxpts, HT_WIN_PASS, lane);
+                const double sum = patch_stage_sum_exact(patch, F, st.count, st.maxpts, lane);
                 if (sum < st.threshold) {  // ccv.js:222
                     alive = false;
                     break;
@@ -380,6 +440,7 @@ __global__ __launch_bounds__(256) void k_scan_deep(const uint8_t *__restrict__ a
                 hits[pos] = h;
             }
         }
+        __builtin_amdgcn_wave_barrier();  // the next window overwrites the patch
     }
 }
 
@@ -472,7 +533,43 @@ ht_status ht_scan_tile_tables(ht_ctx *c) {
     (void)tile_ok;
     HT_HIP(c, hipMalloc(&c->d_tile_feats, tf.size() * sizeof(HtTileFeature)));
     HT_HIP(c, hipMemcpy(c->d_tile_feats, tf.data(), tf.size() * sizeof(HtTileFeature), hipMemcpyHostToDevice));
+
+    // patch-offset form for k_scan_deep
+    std::vector<HtPatchFeature> pf(c->nfeat);
+    for (uint32_t k = 0; k < c->nfeat; k++) {
+        const HtBlobFeature &f = c->h_feats[k];
+        HtPatchFeature &t = pf[k];
+        std::memset(&t, 0, sizeof(t));
+        auto poff = [&](int x, int y, int z) -> uint16_t {
+            if (z == 0) return (uint16_t)(y * (int)c->cw + x);
+            if (z == 1) return (uint16_t)(PATCH1 + y * (int)(c->cw / 2) + x);
+            return (uint16_t)(PATCH2 + y * (int)(c->cw / 4) + x);
+        };
+        int np = 0, nn = 0;
+        for (int q = 0; q < f.size; q++) {
+            if (f.pz[q] >= 0) t.poff[np++] = poff(f.px[q], f.py[q], f.pz[q]);
+            if (f.nz[q] >= 0) t.noff[nn++] = poff(f.nx[q], f.ny[q], f.nz[q]);
+        }
+        for (int q = np; q < HT_MAXPTS; q++) t.poff[q] = t.poff[0];
+        for (int q = nn; q < HT_MAXPTS; q++) t.noff[q] = t.noff[0];
+        t.a0 = f.alpha[0];
+        t.a1 = f.alpha[1];
+        double s0 = t.a0 * 1e8, s1 = t.a1 * 1e8;
+        t.a0i = (int64_t)llround(s0);
+        t.a1i = (int64_t)llround(s1);
+    }
+    HT_HIP(c, hipMalloc(&c->d_patch_feats, pf.size() * sizeof(HtPatchFeature)));
+    HT_HIP(c, hipMemcpy(c->d_patch_feats, pf.data(), pf.size() * sizeof(HtPatchFeature), hipMemcpyHostToDevice));
+
     return HT_OK;
+}
+
+// true iff blob is byte-identical to the cascade ht_cascade_gen.inc was generated from (FNV-1a 64 + length)
+bool ht_scan_is_builtin_cascade(const uint8_t *blob, size_t len) {
+    if (len != HT_GEN_CASCADE_LEN) return false;
+    unsigned long long h = 0xcbf29ce484222325ull;
+    for (size_t i = 0; i < len; i++) h = (h ^ blob[i]) * 0x100000001b3ull;
+    return h == HT_GEN_CASCADE_FNV;
 }
 
 ht_status ht_scan_plan_tiles(ht_ctx *c) {
@@ -529,18 +626,24 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     const uint64_t total64 = (uint64_t)c->tiles_per_frame * (uint64_t)c->nframes;
     if (total64 > 0x7fffff00ull) return ht_fail(c, HT_ERR_INVALID, "ht_detect: batch too large for one launch");
     const uint32_t total = (uint32_t)total64;
+    const bool gen = c->builtin_cascade && !(flags & HT_SCAN_GENERIC);
     {
         HtProfScope ps(c, "scan_tiles");
-        hipLaunchKernelGGL(k_scan_tiles, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                           c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->tiles_per_frame, total, c->d_queue,
-                           c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters);
+        if (gen)
+            hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
+                               c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, c->tiles_per_frame,
+                               total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters);
+        else
+            hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
+                               c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, c->tiles_per_frame,
+                               total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters);
         HT_HIP(c, hipGetLastError());
     }
     if (split < (int)c->nstages) {
         HtProfScope ps(c, "scan_deep");
-        hipLaunchKernelGGL(k_scan_deep, dim3(1024), dim3(256), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
-                           c->d_deep_feats, c->d_stages, (int)c->nstages, split, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity,
-                           c->d_hits, c->hit_capacity, c->d_counters);
+        hipLaunchKernelGGL(k_scan_deep, dim3(2048), dim3(64 * DEEP_WAVES), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
+                           c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
+                           c->hit_capacity, c->d_counters);
         HT_HIP(c, hipGetLastError());
     }
     return HT_OK;

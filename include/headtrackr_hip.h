@@ -44,7 +44,8 @@ enum {
     HT_INPUT_GRAY_IN_R = 1, /* byte 0 of each pixel is already gray: exactly what ccv.detect_objects reads (ccv.js:115,171) */
     HT_SCAN_FUSED_TAIL = 0, /* default scan schedule */
     HT_SCAN_NO_SPLIT = 2,   /* run every cascade stage in the tile kernel (no second "deep" kernel); debugging / A-B */
-    HT_SCAN_SIMPLE = 4      /* one thread per window straight from HBM (slow reference kernel); debugging / A-B */
+    HT_SCAN_SIMPLE = 4,     /* one thread per window straight from HBM (slow reference kernel); debugging / A-B */
+    HT_SCAN_GENERIC = 8     /* table-driven stage code even for the built-in cascade (no generated straight-line stages) */
 };
 
 typedef struct ht_config {

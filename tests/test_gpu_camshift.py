@@ -1,0 +1,133 @@
+"""Parity of the HIP camshift path with the CPU oracle and the reference-JS golden vectors, through the C ABI.
+Integers (search window, centre, size) must match within +-1 px and the angle within +-0.5 deg (BASELINE.json); the
+moment sums are binary64 on both sides but accumulated in a different order, so bit-equality is not promised — in
+practice every case below matches exactly and the test requires >= 95 % exact matches."""
+import math
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from headtrackr_amd import synth
+from headtrackr_amd.api import Context
+from oracle import ht_oracle as ho
+
+pytestmark = pytest.mark.gpu
+CAMSHIFT = load_golden("camshift.json")
+
+ANGLE_TOL = math.radians(0.5)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = Context()
+    yield c
+    c.close()
+
+
+def check(got, want_sw, want, stats):
+    sw = [int(got["sw_x"]), int(got["sw_y"]), int(got["sw_width"]), int(got["sw_height"])]
+    exact = sw == list(want_sw)
+    for a, b in zip(sw[:2], want_sw[:2]):
+        assert abs(a - b) <= 1, (sw, want_sw)
+    for a, b in zip(sw[2:], want_sw[2:]):
+        assert abs(a - b) <= 5, (sw, want_sw)  # 1.1 * (size quantised to multiples of 4)
+    for k in ("x", "y"):
+        assert abs(float(got[k]) - want[k]) <= 1, (k, got, want)
+        exact = exact and float(got[k]) == want[k]
+    for k in ("width", "height"):
+        assert abs(float(got[k]) - want[k]) <= 4, (k, got, want)  # `<< 2` quantisation, camshift.js:240-241
+        exact = exact and float(got[k]) == want[k]
+    wa = want["angle"]
+    if wa is None or (isinstance(wa, float) and math.isnan(wa)):
+        assert math.isnan(float(got["angle"]))
+    else:
+        d = abs(float(got["angle"]) - wa)
+        d = min(d, abs(d - math.pi))  # the angle is defined modulo pi
+        assert d <= ANGLE_TOL, (got, want)
+    stats.append(exact)
+
+
+@pytest.mark.parametrize("case", CAMSHIFT["cases"], ids=lambda c: c["name"])
+def test_golden_sequences(ctx, case):
+    w, h = case["w"], case["h"]
+    frames = [synth.make(g, w, h) for g in case["gen"]]
+    ctx.set_geometry(w, h, 1)
+    ctx.camshift_reserve(1)
+    ctx.upload(frames[0][None])
+    ctx.camshift_init([case["rect"]])
+    stats = []
+    for call in case["calls"]:
+        ctx.upload(frames[call["frame"]][None])
+        got = ctx.camshift_track(1, calc_angles=case["calcAngles"])[0]
+        check(got, call["sw"], call, stats)
+    assert sum(stats) >= 0.95 * len(stats), f"only {sum(stats)}/{len(stats)} calls matched the reference exactly"
+
+
+def test_batch_of_streams_vs_oracle(ctx):
+    """64 independent trackers in one batch (different targets, sizes, colours), 8 frames each, vs the oracle"""
+    w, h, n, steps = 320, 240, 64, 8
+    rng = synth.lcg_stream(99, 16 * n).astype(np.int64) >> 12
+    specs = []
+    for s in range(n):
+        r = rng[16 * s : 16 * s + 16]
+        cx, cy = 60 + int(r[0] % 200), 50 + int(r[1] % 140)
+        a, b = 14 + int(r[2] % 30), 10 + int(r[3] % 20)
+        rot = [(1, 0, 1), (4, 3, 5), (3, 4, 5), (12, 5, 13), (0, 1, 1)][int(r[4] % 5)]
+        color = [(200, 60, 40), (40, 200, 80), (40, 80, 230), (220, 200, 30)][int(r[5] % 4)]
+        specs.append((cx, cy, a, b, rot, color, [int(v % 7) - 3 for v in r[6:6 + 2 * 4]]))
+    seqs = []
+    for s, (cx, cy, a, b, rot, color, walk) in enumerate(specs):
+        fr = []
+        x, y = cx, cy
+        for k in range(steps):
+            fr.append(synth.blob_frame(w, h, x, y, a, b, rot, color, seed=1000 + 31 * s + k))
+            x += walk[(2 * k) % len(walk)]
+            y += walk[(2 * k + 1) % len(walk)]
+        seqs.append(fr)
+    rects = [(cx - a, cy - b, 2 * a, 2 * b) for (cx, cy, a, b, *_rest) in specs]
+    ctx.set_geometry(w, h, n)
+    ctx.camshift_reserve(n)
+    ctx.upload(np.stack([seqs[s][0] for s in range(n)]))
+    ctx.camshift_init(rects)
+    oracles = []
+    for s in range(n):
+        o = ho.Camshift(True)
+        o.init_tracker(seqs[s][0], rects[s])
+        oracles.append(o)
+    stats = []
+    for k in range(1, steps):
+        ctx.upload(np.stack([seqs[s][k] for s in range(n)]))
+        got = ctx.camshift_track(n, calc_angles=True)
+        for s in range(n):
+            sw, to = oracles[s].track(seqs[s][k])
+            check(got[s], sw, to, stats)
+    assert sum(stats) >= 0.95 * len(stats), f"only {sum(stats)}/{len(stats)} track() calls matched the oracle exactly"
+
+
+def test_detect_then_track_like_facetrackr(ctx, golden_facetrackr):
+    """facetrackr's VJ -> CS hand-over (facetrackr.js:97-108,185-217) driven from Python: detect, floor the best rect,
+    initTracker on the COLOUR frame, then track — against the reference-JS state-machine vector"""
+    case = next(c for c in golden_facetrackr["cases"] if c["name"] == "ft_nowb_moving")
+    w, h = case["w"], case["h"]
+    frames = [synth.make(g, w, h) for g in case["gen"]]
+    calls = case["calls"]
+    rects = ctx.detect_objects(frames[0][None], min_neighbors=1)[0]
+    best = rects[int(np.argmax(rects["confidence"]))]  # strict '>' keeps the first maximum (facetrackr.js:161-165)
+    assert calls[0]["detection"] == "VJ"
+    for k in ("x", "y", "width", "height", "confidence"):
+        assert best[k] == calls[0][k]
+    ctx.camshift_reserve(1)
+    ctx.upload(frames[0][None])
+    ctx.camshift_init([[math.floor(best["x"]), math.floor(best["y"]), math.floor(best["width"]), math.floor(best["height"])]])
+    stats = []
+    for i in range(1, len(frames)):
+        ctx.upload(frames[i][None])
+        got = ctx.camshift_track(1, calc_angles=True)[0]
+        assert calls[i]["detection"] == "CS"
+        for k in ("x", "y"):
+            assert abs(float(got[k]) - calls[i][k]) <= 1
+        for k in ("width", "height"):
+            assert abs(float(got[k]) - calls[i][k]) <= 4
+        stats.append(all(float(got[k]) == calls[i][k] for k in ("x", "y", "width", "height")))
+    assert sum(stats) >= len(stats) - 1

@@ -9,6 +9,7 @@ import pytest
 from conftest import load_golden
 from headtrackr_amd import synth
 from headtrackr_amd.api import HT_INPUT_GRAY_IN_R, HT_INPUT_RGBA, HT_SCAN_NO_SPLIT, HT_SCAN_SIMPLE, Context
+from headtrackr_amd.native import HT_SCAN_GENERIC
 from oracle import ht_oracle as ho
 
 pytestmark = pytest.mark.gpu
@@ -100,7 +101,8 @@ def test_pyramid_planes_vs_oracle(ctx, w, h):
                 assert got.shape == want.shape and np.array_equal(got, want), f"frame {f} level {i} slot {s}"
 
 
-@pytest.mark.parametrize("mode", [0, HT_SCAN_NO_SPLIT, HT_SCAN_SIMPLE], ids=["split", "nosplit", "simple"])
+@pytest.mark.parametrize("mode", [0, HT_SCAN_NO_SPLIT, HT_SCAN_SIMPLE, HT_SCAN_GENERIC, HT_SCAN_GENERIC | HT_SCAN_NO_SPLIT],
+                         ids=["gen+deep", "gen-nosplit", "simple", "generic+deep", "generic-nosplit"])
 def test_mixed_batch_hits_vs_oracle(ctx, cascade, mode):
     """N / S / F frames in one batch, every scan schedule: raw hits == oracle, in the reference's order"""
     w, h, n = 320, 240, 12
@@ -142,7 +144,7 @@ def test_full_batch_is_frame_independent(ctx, cascade):
     frames = synth.mixed_batch(n, w, h, seed0=1234)
     hits, counts = ctx.detect_raw(frames)
     assert len(counts) == n
-    starts = np.concatenate([[0], np.cumsum(counts)])
+    starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
     for i in (0, 1, 2, 17, 128, 255):
         alone, _ = ctx.detect_raw(frames[i])
         got = hits[starts[i] : starts[i + 1]].copy()

@@ -169,6 +169,8 @@ def main():
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_frame=b_detect, avg_launch_ms=round(avg_launch_ms, 5))
         dev_ms = sum(per_step.values())
+        ctx.detect_enqueue(a.flags | 16)  # one extra untimed pass with HT_SCAN_STATS for the survival curve
+        ctx.detect_collect(cap=1 << 18)
         sc = ctx.stage_counts()
         extra = dict(kernel_ms_per_step={k: round(v, 5) for k, v in per_step.items()},
                      device_ms_per_step=round(dev_ms, 5),

@@ -215,7 +215,8 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     c->split_stage = std::min<uint32_t>(4, c->nstages);
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     if ((st = upload_cascade(c)) != HT_OK) return bail(st);
-    if (hipMalloc(&c->d_counters, sizeof(HtCounters)) != hipSuccess ||
+    if (hipMalloc(&c->d_stats, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS) != hipSuccess ||
+        hipMalloc(&c->d_counters, sizeof(HtCounters)) != hipSuccess ||
         hipMalloc(&c->d_hits, (size_t)c->hit_capacity * sizeof(ht_hit)) != hipSuccess) {
         c->err = "hipMalloc(hits) failed";
         return bail(HT_ERR_NOMEM);
@@ -249,6 +250,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_frames_own) (void)hipFree(c->d_frames_own);
     if (c->d_hits) (void)hipFree(c->d_hits);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_cs) (void)hipFree(c->d_cs);
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
@@ -476,6 +478,8 @@ extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
     if (!c->d_frames || c->nframes <= 0) return ht_fail(c, HT_ERR_STATE, "ht_detect_enqueue: no frames bound");
     HT_HIP(c, hipSetDevice(c->device));
     HT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(HtCounters), c->stream));
+    c->stats_enqueued = (flags & HT_SCAN_STATS) != 0;
+    if (c->stats_enqueued) HT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS, c->stream));
     ht_status st = ht_launch_pyramid(c, flags);
     if (st != HT_OK) return st;
     st = ht_launch_scan(c, flags);
@@ -499,6 +503,13 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
     HT_HIP(c, hipMemcpyAsync(&c->h_counters, c->d_counters, sizeof(HtCounters), hipMemcpyDeviceToHost, c->stream));
     HT_HIP(c, hipStreamSynchronize(c->stream));
     c->enqueued = false;
+    std::memset(c->h_stage_in, 0, sizeof(c->h_stage_in));
+    if (c->stats_enqueued) {
+        std::vector<unsigned long long> sh((size_t)64 * HT_STAT_SHARDS);
+        HT_HIP(c, hipMemcpy(sh.data(), c->d_stats, sh.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (int r = 0; r < HT_STAT_SHARDS; r++)
+            for (int j = 0; j < 64; j++) c->h_stage_in[j] += sh[(size_t)r * 64 + j];
+    }
     const uint32_t found = c->h_counters.nhits;
     if (total) *total = found;
     if (counts) std::memset(counts, 0, sizeof(uint32_t) * (size_t)c->nframes);
@@ -545,7 +556,7 @@ extern "C" ht_status ht_pyramid_readback(ht_ctx *c, int32_t frame, int32_t level
 
 extern "C" ht_status ht_stage_counts(ht_ctx *c, uint64_t *counts, int32_t n) {
     if (!c || !counts || n < (int32_t)c->nstages + 1) return HT_ERR_INVALID;
-    for (uint32_t j = 0; j <= c->nstages; j++) counts[j] = c->h_counters.stage_in[j];
+    for (uint32_t j = 0; j <= c->nstages; j++) counts[j] = c->h_stage_in[j];
     return HT_OK;
 }
 

@@ -105,13 +105,14 @@ struct HtQueueEntry {
 };
 static_assert(sizeof(HtQueueEntry) == 16, "HtQueueEntry");
 
+#define HT_STAT_SHARDS 256  // rows of 64 u64 counters; a workgroup adds to row (blockIdx & 255)
+
 // Device counters block (zeroed before each batch).
 struct HtCounters {
     uint32_t nhits;        // hits appended (may exceed capacity)
     uint32_t nqueue;       // survivors appended to the deep queue (may exceed capacity)
     uint32_t queue_inline; // survivors that did not fit the queue and were finished inside the tile kernel
     uint32_t pad;
-    unsigned long long stage_in[64];  // windows that entered stage j; [nstages] = full survivors
 };
 
 // camshift per-stream device state (camshift.js:153-160)
@@ -176,6 +177,9 @@ struct ht_ctx {
     HtQueueEntry *d_queue = nullptr;
     HtCounters *d_counters = nullptr;
     HtCounters h_counters;
+    unsigned long long *d_stats = nullptr;      // [HT_STAT_SHARDS][64], only touched with HT_SCAN_STATS
+    unsigned long long h_stage_in[64] = {0};   // windows that entered stage j ([nstages] = full survivors), last collected batch
+    bool stats_enqueued = false;
     bool enqueued = false;
 
     // whitebalance / grayscale scratch

@@ -1,0 +1,479 @@
+// ht_napi.cc — thin N-API (raw node_api.h, no node-addon-api) shim over the C ABI in include/headtrackr_hip.h.
+// It contains no algorithm: argument unpacking, one C-ABI call, result packing.  The JavaScript facade
+// (headtrackr_amd/js/headtrackr.js) builds the reference's API (headtrackr.ccv / camshift / facetrackr) on top of it.
+//
+//   createContext({device, interval, cascade:<Buffer HTCB>, hitCapacity, queueCapacity}) -> ctx (external)
+//   destroy(ctx)
+//   setGeometry(ctx, w, h, maxBatch, Int32Array levelDims | null)
+//   detect(ctx, Uint8Array rgba, n, w, h, flags)        -> {frame,x,y,scale,q,sum, counts}   (sync; the drop-in path)
+//   detectAsync(ctx, rgba, n, w, h, flags)              -> Promise of the same              (napi_create_async_work)
+//   grayscale(ctx, Uint8Array rgba, n, w, h)            -> undefined (in place)
+//   whitebalance(ctx, Uint8Array rgba, n, w, h)         -> Float64Array(n)
+//   camshiftReserve(ctx, nstreams)
+//   camshiftInit(ctx, rgba, n, w, h, first, Int32Array rects[4n])
+//   camshiftTrack(ctx, rgba, n, w, h, first, calcAngles) -> Float64Array(9n): x,y,width,height,angle,swx,swy,sww,swh
+//   info(ctx) -> {levels, windowsPerFrame, pyramidBytesPerFrame}
+#include <node_api.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "headtrackr_hip.h"
+
+namespace {
+
+#define NAPI_OK(call)                                                  \
+    do {                                                               \
+        if ((call) != napi_ok) {                                       \
+            napi_throw_error(env, nullptr, "N-API call failed: " #call); \
+            return nullptr;                                            \
+        }                                                              \
+    } while (0)
+
+napi_value throw_ht(napi_env env, ht_ctx *ctx, ht_status st, const char *where) {
+    std::string msg = std::string(where) + ": status " + std::to_string(st) + ": " + ht_last_error(ctx);
+    napi_throw_error(env, nullptr, msg.c_str());
+    return nullptr;
+}
+
+bool get_ctx(napi_env env, napi_value v, ht_ctx **out) {
+    void *p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+        napi_throw_type_error(env, nullptr, "expected a headtrackr_hip context");
+        return false;
+    }
+    *out = *static_cast<ht_ctx **>(p);
+    if (!*out) {
+        napi_throw_error(env, nullptr, "context was destroyed");
+        return false;
+    }
+    return true;
+}
+
+bool get_i32(napi_env env, napi_value v, int32_t *out) { return napi_get_value_int32(env, v, out) == napi_ok; }
+
+// Uint8Array / Uint8ClampedArray / Buffer -> pointer + length
+bool get_bytes(napi_env env, napi_value v, uint8_t **data, size_t *len) {
+    bool is_ta = false;
+    if (napi_is_typedarray(env, v, &is_ta) == napi_ok && is_ta) {
+        napi_typedarray_type t;
+        size_t n;
+        void *p;
+        napi_value ab;
+        size_t off;
+        if (napi_get_typedarray_info(env, v, &t, &n, &p, &ab, &off) != napi_ok) return false;
+        if (t != napi_uint8_array && t != napi_uint8_clamped_array && t != napi_int8_array) return false;
+        *data = static_cast<uint8_t *>(p);
+        *len = n;
+        return true;
+    }
+    bool is_buf = false;
+    if (napi_is_buffer(env, v, &is_buf) == napi_ok && is_buf) {
+        void *p;
+        if (napi_get_buffer_info(env, v, &p, len) != napi_ok) return false;
+        *data = static_cast<uint8_t *>(p);
+        return true;
+    }
+    return false;
+}
+
+void finalize_ctx(napi_env, void *data, void *) {
+    ht_ctx **slot = static_cast<ht_ctx **>(data);
+    if (*slot) ht_destroy(*slot);
+    delete slot;
+}
+
+napi_value CreateContext(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ht_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.interval = 5;
+    napi_value v;
+    bool has;
+    int32_t i;
+    uint8_t *blob = nullptr;
+    size_t blob_len = 0;
+    if (napi_has_named_property(env, argv[0], "device", &has) == napi_ok && has) {
+        NAPI_OK(napi_get_named_property(env, argv[0], "device", &v));
+        if (get_i32(env, v, &i)) cfg.device = i;
+    }
+    if (napi_has_named_property(env, argv[0], "interval", &has) == napi_ok && has) {
+        NAPI_OK(napi_get_named_property(env, argv[0], "interval", &v));
+        if (get_i32(env, v, &i)) cfg.interval = i;
+    }
+    if (napi_has_named_property(env, argv[0], "hitCapacity", &has) == napi_ok && has) {
+        NAPI_OK(napi_get_named_property(env, argv[0], "hitCapacity", &v));
+        if (get_i32(env, v, &i)) cfg.hit_capacity = (uint32_t)i;
+    }
+    if (napi_has_named_property(env, argv[0], "queueCapacity", &has) == napi_ok && has) {
+        NAPI_OK(napi_get_named_property(env, argv[0], "queueCapacity", &v));
+        if (get_i32(env, v, &i)) cfg.queue_capacity = (uint32_t)i;
+    }
+    NAPI_OK(napi_get_named_property(env, argv[0], "cascade", &v));
+    if (!get_bytes(env, v, &blob, &blob_len)) {
+        napi_throw_type_error(env, nullptr, "createContext: `cascade` must be a Buffer/Uint8Array holding an HTCB blob");
+        return nullptr;
+    }
+    ht_ctx *ctx = nullptr;
+    ht_status st = ht_create(&cfg, blob, blob_len, &ctx);
+    if (st != HT_OK) return throw_ht(env, nullptr, st, "ht_create");
+    ht_ctx **slot = new ht_ctx *(ctx);
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, slot, finalize_ctx, nullptr, &ext));
+    return ext;
+}
+
+napi_value Destroy(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    void *p = nullptr;
+    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+        ht_ctx **slot = static_cast<ht_ctx **>(p);
+        if (*slot) ht_destroy(*slot);
+        *slot = nullptr;
+    }
+    return nullptr;
+}
+
+napi_value SetGeometry(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ht_ctx *ctx;
+    if (!get_ctx(env, argv[0], &ctx)) return nullptr;
+    int32_t w, h, nb;
+    if (!get_i32(env, argv[1], &w) || !get_i32(env, argv[2], &h) || !get_i32(env, argv[3], &nb)) {
+        napi_throw_type_error(env, nullptr, "setGeometry(ctx, w, h, maxBatch, levelDims)");
+        return nullptr;
+    }
+    const int32_t *dims = nullptr;
+    int32_t nlev = 0;
+    bool is_ta = false;
+    if (argc > 4 && napi_is_typedarray(env, argv[4], &is_ta) == napi_ok && is_ta) {
+        napi_typedarray_type t;
+        size_t n;
+        void *p;
+        napi_value ab;
+        size_t off;
+        NAPI_OK(napi_get_typedarray_info(env, argv[4], &t, &n, &p, &ab, &off));
+        if (t != napi_int32_array || (n & 1)) {
+            napi_throw_type_error(env, nullptr, "levelDims must be an Int32Array [w0,h0,w1,h1,...]");
+            return nullptr;
+        }
+        dims = static_cast<const int32_t *>(p);
+        nlev = (int32_t)(n / 2);
+    }
+    ht_status st = ht_set_geometry(ctx, w, h, nb, dims, nlev);
+    if (st != HT_OK) return throw_ht(env, ctx, st, "ht_set_geometry");
+    return nullptr;
+}
+
+// ---- detect ----------------------------------------------------------------------------------------------------
+
+struct DetectJob {
+    ht_ctx *ctx = nullptr;
+    uint8_t *rgba = nullptr;
+    int32_t n = 0, w = 0, h = 0;
+    uint32_t flags = 0;
+    std::vector<ht_hit> hits;
+    std::vector<uint32_t> counts;
+    uint32_t total = 0;
+    ht_status st = HT_OK;
+    std::string err;
+    napi_async_work work = nullptr;
+    napi_deferred deferred = nullptr;
+    napi_ref rgba_ref = nullptr;
+};
+
+void run_detect(DetectJob *j) {
+    uint32_t cap = 4096;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        j->hits.resize(cap);
+        j->counts.assign((size_t)j->n, 0);
+        j->st = ht_detect_batch(j->ctx, j->rgba, j->n, j->w, j->h, (size_t)j->w * j->h * 4, j->flags, j->hits.data(), cap, j->counts.data(), &j->total);
+        if (j->st == HT_ERR_CAPACITY && j->total > cap) {  // caller buffer too small: retry with the exact size
+            cap = j->total;
+            continue;
+        }
+        break;
+    }
+    if (j->st != HT_OK) j->err = ht_last_error(j->ctx);
+}
+
+napi_value pack_hits(napi_env env, const DetectJob &j) {
+    napi_value obj;
+    NAPI_OK(napi_create_object(env, &obj));
+    const size_t n = j.total;
+    struct Col {
+        const char *name;
+        napi_typedarray_type type;
+        size_t esz;
+    } cols[] = {{"frame", napi_uint32_array, 4}, {"x", napi_uint16_array, 2}, {"y", napi_uint16_array, 2},
+                {"scale", napi_uint8_array, 1},  {"q", napi_uint8_array, 1},   {"sum", napi_float64_array, 8}};
+    for (const Col &c : cols) {
+        napi_value ab, ta;
+        void *p = nullptr;
+        NAPI_OK(napi_create_arraybuffer(env, n * c.esz, &p, &ab));
+        for (size_t i = 0; i < n; i++) {
+            const ht_hit &h = j.hits[i];
+            if (c.name[0] == 'f') static_cast<uint32_t *>(p)[i] = h.frame;
+            else if (c.name[0] == 'x') static_cast<uint16_t *>(p)[i] = h.x;
+            else if (c.name[0] == 'y') static_cast<uint16_t *>(p)[i] = h.y;
+            else if (c.name[0] == 's' && c.name[1] == 'c') static_cast<uint8_t *>(p)[i] = h.scale;
+            else if (c.name[0] == 'q') static_cast<uint8_t *>(p)[i] = h.q;
+            else static_cast<double *>(p)[i] = h.sum;
+        }
+        NAPI_OK(napi_create_typedarray(env, c.type, n, ab, 0, &ta));
+        NAPI_OK(napi_set_named_property(env, obj, c.name, ta));
+    }
+    napi_value ab, ta;
+    void *p = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, j.counts.size() * 4, &p, &ab));
+    if (!j.counts.empty()) std::memcpy(p, j.counts.data(), j.counts.size() * 4);
+    NAPI_OK(napi_create_typedarray(env, napi_uint32_array, j.counts.size(), ab, 0, &ta));
+    NAPI_OK(napi_set_named_property(env, obj, "counts", ta));
+    return obj;
+}
+
+bool parse_detect_args(napi_env env, napi_callback_info info, DetectJob *j, napi_value *rgba_val) {
+    size_t argc = 6;
+    napi_value argv[6];
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < 5) {
+        napi_throw_type_error(env, nullptr, "detect(ctx, rgba, n, w, h, flags)");
+        return false;
+    }
+    if (!get_ctx(env, argv[0], &j->ctx)) return false;
+    size_t len = 0;
+    int32_t fl = 0;
+    if (!get_bytes(env, argv[1], &j->rgba, &len) || !get_i32(env, argv[2], &j->n) || !get_i32(env, argv[3], &j->w) || !get_i32(env, argv[4], &j->h)) {
+        napi_throw_type_error(env, nullptr, "detect(ctx, rgba, n, w, h, flags): bad argument");
+        return false;
+    }
+    if (argc > 5) get_i32(env, argv[5], &fl);
+    j->flags = (uint32_t)fl;
+    if (j->n <= 0 || j->w <= 0 || j->h <= 0 || len < (size_t)j->n * j->w * j->h * 4) {
+        napi_throw_range_error(env, nullptr, "detect: rgba buffer smaller than n*w*h*4");
+        return false;
+    }
+    if (rgba_val) *rgba_val = argv[1];
+    return true;
+}
+
+napi_value Detect(napi_env env, napi_callback_info info) {
+    DetectJob j;
+    if (!parse_detect_args(env, info, &j, nullptr)) return nullptr;
+    run_detect(&j);
+    if (j.st != HT_OK) return throw_ht(env, j.ctx, j.st, "ht_detect_batch");
+    return pack_hits(env, j);
+}
+
+void detect_execute(napi_env, void *data) { run_detect(static_cast<DetectJob *>(data)); }
+
+void detect_complete(napi_env env, napi_status, void *data) {
+    DetectJob *j = static_cast<DetectJob *>(data);
+    if (j->st == HT_OK) {
+        napi_value v = pack_hits(env, *j);
+        napi_resolve_deferred(env, j->deferred, v);
+    } else {
+        napi_value msg, err;
+        std::string m = "ht_detect_batch: status " + std::to_string(j->st) + ": " + j->err;
+        napi_create_string_utf8(env, m.c_str(), NAPI_AUTO_LENGTH, &msg);
+        napi_create_error(env, nullptr, msg, &err);
+        napi_reject_deferred(env, j->deferred, err);
+    }
+    napi_delete_reference(env, j->rgba_ref);
+    napi_delete_async_work(env, j->work);
+    delete j;
+}
+
+napi_value DetectAsync(napi_env env, napi_callback_info info) {
+    DetectJob *j = new DetectJob();
+    napi_value rgba_val;
+    if (!parse_detect_args(env, info, j, &rgba_val)) {
+        delete j;
+        return nullptr;
+    }
+    napi_value promise, name;
+    NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
+    NAPI_OK(napi_create_reference(env, rgba_val, 1, &j->rgba_ref));  // keep the frame buffer alive while the GPU works
+    NAPI_OK(napi_create_string_utf8(env, "headtrackr_hip.detect", NAPI_AUTO_LENGTH, &name));
+    NAPI_OK(napi_create_async_work(env, nullptr, name, detect_execute, detect_complete, j, &j->work));
+    NAPI_OK(napi_queue_async_work(env, j->work));
+    return promise;
+}
+
+// ---- grayscale / whitebalance -------------------------------------------------------------------------------------
+
+struct FrameArgs {
+    ht_ctx *ctx;
+    uint8_t *rgba;
+    int32_t n, w, h;
+};
+
+bool parse_frames(napi_env env, napi_value *argv, FrameArgs *a) {
+    size_t len = 0;
+    if (!get_ctx(env, argv[0], &a->ctx)) return false;
+    if (!get_bytes(env, argv[1], &a->rgba, &len) || !get_i32(env, argv[2], &a->n) || !get_i32(env, argv[3], &a->w) || !get_i32(env, argv[4], &a->h) ||
+        a->n <= 0 || a->w <= 0 || a->h <= 0 || len < (size_t)a->n * a->w * a->h * 4) {
+        napi_throw_type_error(env, nullptr, "expected (ctx, Uint8Array rgba, n, w, h, ...) with rgba.length >= n*w*h*4");
+        return false;
+    }
+    return true;
+}
+
+ht_status bind_host_frames(const FrameArgs &a) {
+    ht_status st = ht_set_geometry(a.ctx, a.w, a.h, a.n, nullptr, 0);  // no-op when unchanged
+    if (st != HT_OK) return st;
+    return ht_upload_frames(a.ctx, a.rgba, a.n, (size_t)a.w * a.h * 4);
+}
+
+napi_value Grayscale(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    FrameArgs a;
+    if (argc < 5 || !parse_frames(env, argv, &a)) return nullptr;
+    ht_status st = ht_grayscale_batch(a.ctx, a.rgba, a.n, a.w, a.h, (size_t)a.w * a.h * 4);
+    if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_grayscale_batch");
+    return nullptr;
+}
+
+napi_value Whitebalance(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    FrameArgs a;
+    if (argc < 5 || !parse_frames(env, argv, &a)) return nullptr;
+    ht_status st = bind_host_frames(a);
+    if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_upload_frames");
+    napi_value ab, ta;
+    void *p = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)a.n * 8, &p, &ab));
+    st = ht_whitebalance_batch(a.ctx, static_cast<double *>(p), a.n);
+    if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_whitebalance_batch");
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, (size_t)a.n, ab, 0, &ta));
+    return ta;
+}
+
+// ---- camshift ---------------------------------------------------------------------------------------------------
+
+napi_value CamshiftReserve(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ht_ctx *ctx;
+    int32_t n;
+    if (!get_ctx(env, argv[0], &ctx)) return nullptr;
+    if (!get_i32(env, argv[1], &n)) {
+        napi_throw_type_error(env, nullptr, "camshiftReserve(ctx, nstreams)");
+        return nullptr;
+    }
+    ht_status st = ht_camshift_reserve(ctx, n);
+    if (st != HT_OK) return throw_ht(env, ctx, st, "ht_camshift_reserve");
+    return nullptr;
+}
+
+napi_value CamshiftInit(napi_env env, napi_callback_info info) {
+    size_t argc = 7;
+    napi_value argv[7];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    FrameArgs a;
+    if (argc < 7 || !parse_frames(env, argv, &a)) return nullptr;
+    int32_t first;
+    napi_typedarray_type t;
+    size_t n;
+    void *p;
+    napi_value ab;
+    size_t off;
+    if (!get_i32(env, argv[5], &first) || napi_get_typedarray_info(env, argv[6], &t, &n, &p, &ab, &off) != napi_ok || t != napi_int32_array ||
+        n < (size_t)a.n * 4) {
+        napi_throw_type_error(env, nullptr, "camshiftInit(ctx, rgba, n, w, h, first, Int32Array rects[4n])");
+        return nullptr;
+    }
+    ht_status st = bind_host_frames(a);
+    if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_upload_frames");
+    st = ht_camshift_init_batch(a.ctx, first, a.n, static_cast<const ht_cs_rect *>(p));
+    if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_camshift_init_batch");
+    return nullptr;
+}
+
+napi_value CamshiftTrack(napi_env env, napi_callback_info info) {
+    size_t argc = 7;
+    napi_value argv[7];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    FrameArgs a;
+    if (argc < 7 || !parse_frames(env, argv, &a)) return nullptr;
+    int32_t first, calc;
+    if (!get_i32(env, argv[5], &first) || !get_i32(env, argv[6], &calc)) {
+        napi_throw_type_error(env, nullptr, "camshiftTrack(ctx, rgba, n, w, h, first, calcAngles)");
+        return nullptr;
+    }
+    ht_status st = bind_host_frames(a);
+    if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_upload_frames");
+    std::vector<ht_cs_trackobj> out((size_t)a.n);
+    st = ht_camshift_track_batch(a.ctx, first, a.n, calc, out.data());
+    if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_camshift_track_batch");
+    napi_value ab, ta;
+    void *p = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)a.n * 9 * 8, &p, &ab));
+    double *d = static_cast<double *>(p);
+    for (int i = 0; i < a.n; i++) {
+        const ht_cs_trackobj &o = out[i];
+        double *r = d + 9 * i;
+        r[0] = o.x, r[1] = o.y, r[2] = o.width, r[3] = o.height, r[4] = o.angle;
+        r[5] = o.sw_x, r[6] = o.sw_y, r[7] = o.sw_width, r[8] = o.sw_height;
+    }
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, (size_t)a.n * 9, ab, 0, &ta));
+    return ta;
+}
+
+napi_value Info(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    ht_ctx *ctx;
+    if (!get_ctx(env, argv[0], &ctx)) return nullptr;
+    napi_value obj, v;
+    NAPI_OK(napi_create_object(env, &obj));
+    NAPI_OK(napi_create_int32(env, ht_num_levels(ctx), &v));
+    NAPI_OK(napi_set_named_property(env, obj, "levels", v));
+    NAPI_OK(napi_create_double(env, (double)ht_windows_per_frame(ctx), &v));
+    NAPI_OK(napi_set_named_property(env, obj, "windowsPerFrame", v));
+    NAPI_OK(napi_create_double(env, (double)ht_pyramid_bytes_per_frame(ctx), &v));
+    NAPI_OK(napi_set_named_property(env, obj, "pyramidBytesPerFrame", v));
+    return obj;
+}
+
+napi_value Init(napi_env env, napi_value exports) {
+    struct {
+        const char *name;
+        napi_callback fn;
+    } fns[] = {{"createContext", CreateContext}, {"destroy", Destroy},         {"setGeometry", SetGeometry},
+               {"detect", Detect},               {"detectAsync", DetectAsync}, {"grayscale", Grayscale},
+               {"whitebalance", Whitebalance},   {"camshiftReserve", CamshiftReserve},
+               {"camshiftInit", CamshiftInit},   {"camshiftTrack", CamshiftTrack}, {"info", Info}};
+    for (auto &f : fns) {
+        napi_value fn;
+        if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn) != napi_ok) return nullptr;
+        if (napi_set_named_property(env, exports, f.name, fn) != napi_ok) return nullptr;
+    }
+    napi_value v;
+    napi_create_int32(env, ht_abi_version(), &v);
+    napi_set_named_property(env, exports, "abiVersion", v);
+    napi_create_int32(env, HT_INPUT_GRAY_IN_R, &v);
+    napi_set_named_property(env, exports, "INPUT_GRAY_IN_R", v);
+    napi_create_int32(env, HT_INPUT_RGBA, &v);
+    napi_set_named_property(env, exports, "INPUT_RGBA", v);
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

@@ -24,6 +24,7 @@
 //   * k_scan_simple — one thread per window straight from HBM; slow, kept as an independent cross-check.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "ht_internal.h"
@@ -117,9 +118,9 @@ __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict_
                                                    const HtDevLevel *__restrict__ levels, const HtScanScale *__restrict__ scales,
                                                    int nscales, const HtTileFeature *__restrict__ feats,
                                                    const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,
-                                                   uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
+                                                   int stop_stage, uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
                                                    uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
-                                                   HtCounters *__restrict__ ctr) {
+                                                   HtCounters *__restrict__ ctr, unsigned long long *__restrict__ stats) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TILE_BYTES];
     __shared__ uint16_t qbuf[2][MAXWIN];
     __shared__ uint32_t s_nout;
@@ -141,6 +142,9 @@ __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict_
     const HtDevLevel L0 = levels[S.l0], L1 = levels[S.l1], L2 = levels[S.l2];
     const uint8_t *fbase = arena + (uint64_t)frame * arena_stride;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    // optional survival statistics: one of HT_STAT_SHARDS counter rows per workgroup (same-address atomics from 15k
+    // workgroups serialise in L2 at ~90/us, which would dominate the kernel)
+    unsigned long long *my_stats = stats ? stats + (size_t)(blockIdx.x & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
 
     // ---- stage the three planes into LDS --------------------------------------------------------------------
     {   // plane 0: level i, origin (2*X0, 2*Y0), rows of PITCH0 bytes as aligned dwords
@@ -181,6 +185,7 @@ __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict_
     int cur = 0;
     bool pushed = (split >= nstages);
     for (int s = 0; s < nstages; s++) {
+        if (s == stop_stage) return;  // measurement knob (HT_DEBUG_STOP_STAGE): results are incomplete when set
         const HtDevStage st = stages[s];
         // hand-off rule: from stage `split` on, survivors leave for k_scan_deep (one wavefront per window, features
         // across lanes) as soon as that is cheaper than keeping them on a few lanes of this workgroup
@@ -213,7 +218,6 @@ __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict_
         }
         const HtTileFeature *F = feats + st.first;
         const bool last = (s == nstages - 1);
-        uint32_t n_valid = 0;
         for (uint32_t base = 0; base < n_in; base += NT) {
             const uint32_t pos = base + tid;
             bool valid = pos < n_in;
@@ -235,7 +239,6 @@ __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict_
                 pass = valid && !(sum < st.threshold);  // ccv.js:222
             }
             const unsigned long long m = __ballot(pass);
-            if (s == 0) n_valid += __popcll(__ballot(valid));
             if (m) {
                 const uint32_t cnt = __popcll(m);
                 const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -260,15 +263,11 @@ __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict_
                         h.sum = sum;  // ccv.js:233
                         hits[b0 + pre] = h;
                     }
-                    if (lane == 0) atomicAdd(&ctr->stage_in[nstages], (unsigned long long)cnt);
+                    if (lane == 0 && my_stats) atomicAdd(&my_stats[nstages], (unsigned long long)cnt);
                 }
             }
         }
-        if (s == 0) {
-            if (lane == 0 && n_valid) atomicAdd(&ctr->stage_in[0], (unsigned long long)n_valid);
-        } else if (tid == 0) {
-            atomicAdd(&ctr->stage_in[s], (unsigned long long)n_in);
-        }
+        if (tid == 0 && my_stats) atomicAdd(&my_stats[s], (unsigned long long)(s == 0 ? (uint32_t)(tw * th) : n_in));
         __syncthreads();
         n_in = s_nout;
         __syncthreads();
@@ -373,11 +372,13 @@ __global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__
                                                                const HtPatchFeature *__restrict__ feats,
                                                                const HtDevStage *__restrict__ stages, int nstages, int use_int,
                                                                const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
-                                                               ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr) {
+                                                               ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr,
+                                                               unsigned long long *__restrict__ stats) {
     __shared__ __attribute__((aligned(16))) uint8_t s_patch[DEEP_WAVES][PATCH_BYTES];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     uint8_t *patch = s_patch[wv];
     const uint32_t wave = blockIdx.x * DEEP_WAVES + wv, nwaves = gridDim.x * DEEP_WAVES;
+    unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
     const uint32_t n = min(ctr->nqueue, queue_cap);
     for (uint32_t e = wave; e < n; e += nwaves) {
         const HtQueueEntry ent = queue[e];
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__
         for (int j = (int)ent.pad; j < nstages; j++) {
             const HtDevStage st = stages[j];
             const HtPatchFeature *F = feats + st.first;
-            if (lane == 0) atomicAdd(&ctr->stage_in[j], 1ull);
+            if (lane == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
             bool need_exact = true;
             if (use_int) {
                 long long acc = 0;
@@ -425,7 +426,7 @@ __global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__
             }
         }
         if (alive && lane == 0) {
-            atomicAdd(&ctr->stage_in[nstages], 1ull);
+            if (my_stats) atomicAdd(&my_stats[nstages], 1ull);
             const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
             if (pos < hit_cap) {
                 ht_hit h;
@@ -452,7 +453,8 @@ __global__ __launch_bounds__(256) void k_scan_simple(const uint8_t *__restrict__
                                                      const HtScanScale *__restrict__ scales, int nscales, uint32_t windows_per_frame,
                                                      const HtDeepFeature *__restrict__ feats, const HtDevStage *__restrict__ stages,
                                                      int nstages, ht_hit *__restrict__ hits, uint32_t hit_cap,
-                                                     HtCounters *__restrict__ ctr) {
+                                                     HtCounters *__restrict__ ctr, unsigned long long *__restrict__ stats) {
+    unsigned long long *my_stats = stats ? stats + (size_t)(blockIdx.x & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
     const uint32_t wi = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t frame = blockIdx.y;
     const uint32_t lane = threadIdx.x & 63u;
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(256) void k_scan_simple(const uint8_t *__restrict__
     for (int j = 0; j < nstages; j++) {
         const unsigned long long m = __ballot(alive);
         if (!m) break;
-        if (lane == 0) atomicAdd(&ctr->stage_in[j], (unsigned long long)__popcll(m));
+        if (lane == 0 && my_stats) atomicAdd(&my_stats[j], (unsigned long long)__popcll(m));
         const HtDevStage st = stages[j];
         const HtDeepFeature *F = feats + st.first;
         sum = 0.0;
@@ -482,7 +484,7 @@ __global__ __launch_bounds__(256) void k_scan_simple(const uint8_t *__restrict__
         }
     }
     if (alive) {
-        atomicAdd(&ctr->stage_in[nstages], 1ull);
+        if (my_stats) atomicAdd(&my_stats[nstages], 1ull);
         const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
         if (pos < hit_cap) {
             ht_hit h;
@@ -612,13 +614,14 @@ ht_status ht_scan_plan_tiles(ht_ctx *c) {
 ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     if (c->h_scales.empty() || c->tiles_per_frame == 0) return HT_OK;  // image too small for any window
     const int nscales = (int)c->h_scales.size();
+    unsigned long long *stats = (flags & HT_SCAN_STATS) ? c->d_stats : nullptr;
     const bool tile_ok = (c->cw == 24 && c->ch == 24);
     if ((flags & HT_SCAN_SIMPLE) || !tile_ok) {
         HtProfScope ps(c, "scan_simple");
         dim3 grid((uint32_t)((c->windows_per_frame + 255) / 256), c->nframes);
         hipLaunchKernelGGL(k_scan_simple, grid, dim3(256), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next, c->d_scales,
                            nscales, (uint32_t)c->windows_per_frame, c->d_deep_feats, c->d_stages, (int)c->nstages, c->d_hits,
-                           c->hit_capacity, c->d_counters);
+                           c->hit_capacity, c->d_counters, stats);
         HT_HIP(c, hipGetLastError());
         return HT_OK;
     }
@@ -627,23 +630,27 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     if (total64 > 0x7fffff00ull) return ht_fail(c, HT_ERR_INVALID, "ht_detect: batch too large for one launch");
     const uint32_t total = (uint32_t)total64;
     const bool gen = c->builtin_cascade && !(flags & HT_SCAN_GENERIC);
+    // measurement knobs (never set in production): stop the tile kernel before a stage / tune the hand-off rule
+    const char *dbg_stop = getenv("HT_DEBUG_STOP_STAGE"), *dbg_bias = getenv("HT_DEBUG_DEEP_BIAS");
+    const int stop_stage = dbg_stop ? atoi(dbg_stop) : -1;
+    if (dbg_bias) c->deep_bias = (uint32_t)atoi(dbg_bias);
     {
         HtProfScope ps(c, "scan_tiles");
         if (gen)
             hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                               c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, c->tiles_per_frame,
-                               total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters);
+                               c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, c->tiles_per_frame,
+                               total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
         else
             hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                               c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, c->tiles_per_frame,
-                               total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters);
+                               c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, c->tiles_per_frame,
+                               total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
         HT_HIP(c, hipGetLastError());
     }
     if (split < (int)c->nstages) {
         HtProfScope ps(c, "scan_deep");
         hipLaunchKernelGGL(k_scan_deep, dim3(2048), dim3(64 * DEEP_WAVES), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                            c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
-                           c->hit_capacity, c->d_counters);
+                           c->hit_capacity, c->d_counters, stats);
         HT_HIP(c, hipGetLastError());
     }
     return HT_OK;

@@ -1,0 +1,480 @@
+'use strict';
+/*
+ * headtrackr.js (MI355X edition) — JavaScript host of the HIP detect / track hot path.
+ *
+ * Exposes the reference's per-frame API under the reference's names so that code written against
+ * auduno/headtrackr's `headtrackr.ccv`, `headtrackr.cascade`, `headtrackr.camshift`, `headtrackr.facetrackr` and
+ * `headtrackr.getWhitebalance` runs unchanged, with the pixel work done by libheadtrackr_hip.so through the N-API addon
+ * (headtrackr_hip.node, C ABI in include/headtrackr_hip.h).  Reference citations are /root/reference/src/<file>:<line>.
+ *
+ *   ccv.grayscale(canvas)                               ccv.js:22-32     -> ht_grayscale_batch
+ *   ccv.detect_objects(canvas,cascade,interval,min_nb)  ccv.js:109-333   -> ht_detect_batch (pyramid + cascade scan);
+ *                                                                            seq construction + grouping stay in JS
+ *   ccv.array_group(seq,gfunc)                          ccv.js:34-107    (host, O(n^2) on a few dozen rects)
+ *   camshift.Tracker / Histogram / Moments / Rectangle / TrackObj          camshift.js:49-378 -> ht_camshift_*
+ *   facetrackr.Tracker / TrackObj                       facetrackr.js:37-255  (state machine WB -> VJ -> CS)
+ *   getWhitebalance(canvas)                             whitebalance.js:5-30 -> ht_whitebalance_batch
+ * plus batch entry points that the single-frame browser API has no room for:
+ *   detect_objects_batch(frames, w, h, cascade, interval, min_neighbors)  -> Promise<Array<Array<rect>>>
+ *
+ * "canvas" is anything with width, height and getContext('2d') -> {getImageData, putImageData, drawImage,
+ * createImageData}; ./canvas.js provides one for Node.  Failure conventions are the reference's: empty arrays,
+ * confidence -10000, width == height == 0 — plus exceptions only for misuse of the native layer (no GPU, bad cascade).
+ */
+const path = require('path');
+const fs = require('fs');
+const pack = require('./cascade_pack.js');
+
+let native = null;
+function addon() {
+  if (!native) {
+    try {
+      native = require('./headtrackr_hip.node');
+    } catch (e) {
+      throw new Error('headtrackr_hip.node could not be loaded (' + e.message + '); build it with `python -m headtrackr_amd.build`. ' +
+        'There is no JavaScript fallback for the detection / tracking kernels.');
+    }
+  }
+  return native;
+}
+
+const headtrackr = {};
+headtrackr.rev = 2; /* main.js:13 */
+
+/* ---- cascade ---------------------------------------------------------------------------------------------------- */
+
+let builtinCascade = null;
+Object.defineProperty(headtrackr, 'cascade', { /* cascade.js:19: the trained face cascade, rebuilt from data/cascade.bin */
+  enumerable: true,
+  get: function () {
+    if (!builtinCascade) builtinCascade = pack.unpackCascade(fs.readFileSync(path.join(__dirname, '..', 'data', 'cascade.bin')));
+    return builtinCascade;
+  }
+});
+
+/* one native context per (cascade object, interval); contexts own device memory, so they are cached */
+const contexts = new WeakMap();
+function contextFor(cascade, interval) {
+  let perCascade = contexts.get(cascade);
+  if (!perCascade) { perCascade = new Map(); contexts.set(cascade, perCascade); }
+  let c = perCascade.get(interval);
+  if (!c) {
+    c = { handle: addon().createContext({ cascade: pack.packCascade(cascade), interval: interval, device: headtrackr.device | 0 }),
+      w: 0, h: 0, batch: 0 };
+    perCascade.set(interval, c);
+  }
+  return c;
+}
+headtrackr.device = 0; /* HIP device ordinal used for new contexts */
+
+/* pyramid level sizes exactly as ccv.js:110-127 computes them (Math.pow / Math.floor in V8), handed to the native
+ * side so that no libm difference can move a level boundary */
+function levelDims(w, h, cascade, interval) {
+  const scale = Math.pow(2, 1 / (interval + 1));
+  const next = interval + 1;
+  const upto = Math.floor(Math.log(Math.min(cascade.width, cascade.height)) / Math.log(scale));
+  const n = upto + next * 2;
+  const d = new Int32Array(2 * n);
+  d[0] = w; d[1] = h;
+  for (let i = 1; i <= interval; i++) {
+    d[2 * i] = Math.floor(w / Math.pow(scale, i));
+    d[2 * i + 1] = Math.floor(h / Math.pow(scale, i));
+  }
+  for (let i = next; i < n; i++) {
+    d[2 * i] = Math.floor(d[2 * (i - next)] / 2);
+    d[2 * i + 1] = Math.floor(d[2 * (i - next) + 1] / 2);
+  }
+  return d;
+}
+
+function ensureGeometry(c, w, h, batch, cascade, interval) {
+  if (c.w !== w || c.h !== h || c.batch < batch) {
+    addon().setGeometry(c.handle, w, h, batch, levelDims(w, h, cascade, interval));
+    c.w = w; c.h = h; c.batch = batch;
+  }
+}
+
+/* ---- ccv ------------------------------------------------------------------------------------------------------------ */
+
+headtrackr.ccv = {};
+
+headtrackr.ccv.grayscale = function (canvas) { /* ccv.js:22-32, in place, returns the canvas */
+  const ctx = canvas.getContext('2d');
+  const img = ctx.getImageData(0, 0, canvas.width, canvas.height);
+  if (canvas.width > 0 && canvas.height > 0) {
+    const c = contextFor(headtrackr.cascade, 5);
+    addon().grayscale(c.handle, img.data, 1, canvas.width, canvas.height);
+  }
+  ctx.putImageData(img, 0, 0);
+  return canvas;
+};
+
+/* union-find grouping with rank + path compression; class numbers in first-seen order (ccv.js:34-107) */
+headtrackr.ccv.array_group = function (seq, gfunc) {
+  const n = seq.length;
+  const parent = new Int32Array(n).fill(-1), rank = new Int32Array(n);
+  const rootOf = function (i) { while (parent[i] !== -1) i = parent[i]; return i; };
+  const compress = function (i, root) { while (parent[i] !== -1) { const t = i; i = parent[i]; parent[t] = root; } };
+  for (let i = 0; i < n; i++) {
+    if (!seq[i]) continue;
+    let root = rootOf(i);
+    for (let j = 0; j < n; j++) {
+      if (i === j || !seq[j] || !gfunc(seq[i], seq[j])) continue;
+      const root2 = rootOf(j);
+      if (root2 === root) continue;
+      if (rank[root] > rank[root2]) {
+        parent[root2] = root;
+      } else {
+        parent[root] = root2;
+        if (rank[root] === rank[root2]) rank[root2]++;
+        root = root2;
+      }
+      compress(j, root);
+      compress(i, root);
+    }
+  }
+  const index = new Array(n);
+  let cat = 0;
+  for (let i = 0; i < n; i++) {
+    let j = -1;
+    if (seq[i]) {
+      const r = rootOf(i);
+      if (rank[r] >= 0) rank[r] = ~cat++;
+      j = ~rank[r];
+    }
+    index[i] = j;
+  }
+  return { index: index, cat: cat };
+};
+
+/* raw hits (index form) -> the reference's `seq` (ccv.js:227-234), scale_x by repeated multiplication (ccv.js:244-245) */
+function hitsToSeq(hits, from, to, cascade, interval) {
+  const scale = Math.pow(2, 1 / (interval + 1));
+  const s = [1];
+  const seq = [];
+  for (let k = from; k < to; k++) {
+    const i = hits.scale[k], q = hits.q[k];
+    while (s.length <= i) s.push(s[s.length - 1] * scale);
+    seq.push({ x: (hits.x[k] * 4 + (q & 1) * 2) * s[i], y: (hits.y[k] * 4 + (q >> 1) * 2) * s[i],
+      width: cascade.width * s[i], height: cascade.height * s[i], neighbor: 1, confidence: hits.sum[k] });
+  }
+  return seq;
+}
+
+/* ccv.js:249-332: grouping, per-class mean + 0.5, nested-rectangle filter */
+function groupSeq(seq, min_neighbors) {
+  if (!(min_neighbors > 0)) return seq;
+  const result = headtrackr.ccv.array_group(seq, function (r1, r2) {
+    const distance = Math.floor(r1.width * 0.25 + 0.5);
+    return r2.x <= r1.x + distance && r2.x >= r1.x - distance && r2.y <= r1.y + distance && r2.y >= r1.y - distance &&
+      r2.width <= Math.floor(r1.width * 1.5 + 0.5) && Math.floor(r2.width * 1.5 + 0.5) >= r1.width;
+  });
+  const comps = [];
+  for (let i = 0; i <= result.cat; i++) comps.push({ neighbors: 0, x: 0, y: 0, width: 0, height: 0, confidence: 0 });
+  for (let i = 0; i < seq.length; i++) {
+    const r = seq[i], c = comps[result.index[i]];
+    if (c.neighbors === 0) c.confidence = r.confidence;
+    ++c.neighbors;
+    c.x += r.x; c.y += r.y; c.width += r.width; c.height += r.height;
+    c.confidence = Math.max(c.confidence, r.confidence);
+  }
+  const seq2 = [];
+  for (let i = 0; i < result.cat; i++) {
+    const c = comps[i], n = c.neighbors;
+    if (n >= min_neighbors) {
+      seq2.push({ x: (c.x * 2 + n) / (2 * n), y: (c.y * 2 + n) / (2 * n), width: (c.width * 2 + n) / (2 * n),
+        height: (c.height * 2 + n) / (2 * n), neighbors: n, confidence: c.confidence });
+    }
+  }
+  const out = [];
+  for (let i = 0; i < seq2.length; i++) {
+    const r1 = seq2[i];
+    let keep = true;
+    for (let j = 0; j < seq2.length && keep; j++) {
+      const r2 = seq2[j], distance = Math.floor(r2.width * 0.25 + 0.5);
+      if (i !== j && r1.x >= r2.x - distance && r1.y >= r2.y - distance && r1.x + r1.width <= r2.x + r2.width + distance &&
+          r1.y + r1.height <= r2.y + r2.height + distance && (r2.neighbors > Math.max(3, r1.neighbors) || r1.neighbors < 3)) keep = false;
+    }
+    if (keep) out.push(r1);
+  }
+  return out;
+}
+
+headtrackr.ccv._group = groupSeq; /* exposed for tests */
+
+/* ccv.js:109: `canvas` is expected to be gray already (byte 0 of each pixel is what the detector reads) */
+headtrackr.ccv.detect_objects = function (canvas, cascade, interval, min_neighbors) {
+  const w = canvas.width, h = canvas.height;
+  const img = canvas.getContext('2d').getImageData(0, 0, w, h);
+  canvas.data = img.data; /* the reference hangs the pixels on the caller's canvas (ccv.js:115) */
+  if (!(w > 0 && h > 0)) return [];
+  const c = contextFor(cascade, interval);
+  ensureGeometry(c, w, h, 1, cascade, interval);
+  const hits = addon().detect(c.handle, img.data, 1, w, h, addon().INPUT_GRAY_IN_R);
+  return groupSeq(hitsToSeq(hits, 0, hits.sum.length, cascade, interval), min_neighbors);
+};
+
+/* fused colour path used by facetrackr: ccv.grayscale + ccv.detect_objects without the intermediate canvas copy */
+headtrackr.ccv.detect_objects_rgba = function (rgba, w, h, cascade, interval, min_neighbors) {
+  if (!(w > 0 && h > 0)) return [];
+  const c = contextFor(cascade, interval);
+  ensureGeometry(c, w, h, 1, cascade, interval);
+  const hits = addon().detect(c.handle, rgba, 1, w, h, addon().INPUT_RGBA);
+  return groupSeq(hitsToSeq(hits, 0, hits.sum.length, cascade, interval), min_neighbors);
+};
+
+/* n RGBA frames (one Uint8Array of n*w*h*4 bytes) -> Promise of n result lists; runs on the libuv pool */
+headtrackr.ccv.detect_objects_batch = function (frames, n, w, h, cascade, interval, min_neighbors) {
+  cascade = cascade || headtrackr.cascade;
+  interval = interval === undefined ? 5 : interval;
+  min_neighbors = min_neighbors === undefined ? 1 : min_neighbors;
+  const c = contextFor(cascade, interval);
+  ensureGeometry(c, w, h, n, cascade, interval);
+  return addon().detectAsync(c.handle, frames, n, w, h, addon().INPUT_RGBA).then(function (hits) {
+    const out = [];
+    let k = 0;
+    for (let f = 0; f < n; f++) {
+      out.push(groupSeq(hitsToSeq(hits, k, k + hits.counts[f], cascade, interval), min_neighbors));
+      k += hits.counts[f];
+    }
+    return out;
+  });
+};
+
+/* ---- whitebalance ----------------------------------------------------------------------------------------------------- */
+
+headtrackr.getWhitebalance = function (canvas) { /* whitebalance.js:5-30 */
+  const img = canvas.getContext('2d').getImageData(0, 0, canvas.width, canvas.height);
+  if (!(img.width > 0 && img.height > 0)) return NaN; /* 0/0 in the reference */
+  const c = contextFor(headtrackr.cascade, 5);
+  return addon().whitebalance(c.handle, img.data, 1, img.width, img.height)[0];
+};
+
+/* ---- camshift ----------------------------------------------------------------------------------------------------------- */
+
+headtrackr.camshift = {};
+
+headtrackr.camshift.Histogram = function (imgdata) { /* camshift.js:49-72 (host-side; used by the debug getters) */
+  this.size = 4096;
+  const bins = new Uint32Array(4096);
+  for (let x = 0, il = imgdata.length; x < il; x += 4) bins[256 * (imgdata[x] >> 4) + 16 * (imgdata[x + 1] >> 4) + (imgdata[x + 2] >> 4)] += 1;
+  this.getBin = function (index) { return bins[index]; };
+};
+
+headtrackr.camshift.Moments = function (data, x, y, w, h, second) { /* camshift.js:79-120 (host-side, for API completeness) */
+  this.m00 = 0; this.m01 = 0; this.m10 = 0; this.m11 = 0; this.m02 = 0; this.m20 = 0;
+  for (let i = x; i < w; i++) {
+    const col = data[i], vx = i - x;
+    for (let j = y; j < h; j++) {
+      const val = col[j], vy = j - y;
+      this.m00 += val; this.m01 += vy * val; this.m10 += vx * val;
+      if (second) { this.m11 += vx * vy * val; this.m02 += vy * vy * val; this.m20 += vx * vx * val; }
+    }
+  }
+  this.invM00 = 1 / this.m00;
+  this.xc = this.m10 * this.invM00;
+  this.yc = this.m01 * this.invM00;
+  this.mu00 = this.m00; this.mu01 = 0; this.mu10 = 0;
+  if (second) {
+    this.mu20 = this.m20 - this.m10 * this.xc;
+    this.mu02 = this.m02 - this.m01 * this.yc;
+    this.mu11 = this.m11 - this.m01 * this.xc;
+  }
+};
+
+headtrackr.camshift.Rectangle = function (x, y, w, h) { /* camshift.js:127-141 */
+  this.x = x; this.y = y; this.width = w; this.height = h;
+  this.clone = function () { return new headtrackr.camshift.Rectangle(this.x, this.y, this.width, this.height); };
+};
+
+headtrackr.camshift.TrackObj = function () { /* camshift.js:362-378 */
+  this.height = 0; this.width = 0; this.angle = 0; this.x = 0; this.y = 0;
+  this.clone = function () {
+    const c = new headtrackr.camshift.TrackObj();
+    c.height = this.height; c.width = this.width; c.angle = this.angle; c.x = this.x; c.y = this.y;
+    return c;
+  };
+};
+
+/* every camshift.Tracker owns one device-side stream slot of a shared context */
+const csPool = { ctx: null, next: 0, free: [] };
+function csSlot() {
+  if (!csPool.ctx) csPool.ctx = contextFor(headtrackr.cascade, 5);
+  const slot = csPool.free.length ? csPool.free.pop() : csPool.next++;
+  addon().camshiftReserve(csPool.ctx.handle, Math.max(csPool.next, 1));
+  return slot;
+}
+
+headtrackr.camshift.Tracker = function (params) { /* camshift.js:148-354 */
+  if (params === undefined) params = {};
+  if (params.calcAngles === undefined) params.calcAngles = true;
+  const slot = csSlot();
+  let searchWindow = null, trackObj = null, lastFrame = null, modelRect = null, modelFrame = null, canvasCtx = null;
+
+  this.getSearchWindow = function () { return searchWindow.clone(); };
+  this.getTrackObj = function () { return trackObj.clone(); };
+
+  this.initTracker = function (canvas, trackedArea) { /* camshift.js:198-211 */
+    canvasCtx = canvas.getContext('2d');
+    const img = canvasCtx.getImageData(0, 0, canvas.width, canvas.height);
+    const rect = new Int32Array([trackedArea.x, trackedArea.y, trackedArea.width, trackedArea.height]);
+    addon().camshiftInit(csPool.ctx.handle, img.data, 1, canvas.width, canvas.height, slot, rect);
+    modelFrame = img; modelRect = trackedArea.clone();
+    searchWindow = trackedArea.clone();
+    trackObj = new headtrackr.camshift.TrackObj();
+  };
+
+  this.track = function (canvas) { /* camshift.js:213-259 */
+    const img = canvas.getContext('2d').getImageData(0, 0, canvas.width, canvas.height);
+    if (img.width === 0 || img.height === 0) return;
+    lastFrame = img;
+    const r = addon().camshiftTrack(csPool.ctx.handle, img.data, 1, img.width, img.height, slot, params.calcAngles ? 1 : 0);
+    trackObj.x = r[0]; trackObj.y = r[1]; trackObj.width = r[2]; trackObj.height = r[3]; trackObj.angle = r[4];
+    searchWindow.x = r[5]; searchWindow.y = r[6]; searchWindow.width = r[7]; searchWindow.height = r[8];
+  };
+
+  /* debug getters: the back-projection is never materialised on the device (only these two functions can observe it),
+   * so it is rebuilt here on demand from the last frame (camshift.js:172-196, 314-353) */
+  this.getPdf = function () {
+    if (!lastFrame || !modelFrame) return undefined;
+    const w = lastFrame.width, h = lastFrame.height, d = lastFrame.data;
+    const mr = modelRect, mw = modelFrame.width, mh = modelFrame.height, md = modelFrame.data;
+    const model = new Uint32Array(4096);
+    for (let y = mr.y; y < mr.y + mr.height; y++) {
+      for (let x = mr.x; x < mr.x + mr.width; x++) {
+        if (x >= 0 && x < mw && y >= 0 && y < mh) {
+          const p = (y * mw + x) * 4;
+          model[256 * (md[p] >> 4) + 16 * (md[p + 1] >> 4) + (md[p + 2] >> 4)]++;
+        } else model[0]++;
+      }
+    }
+    const cur = new headtrackr.camshift.Histogram(d);
+    const weights = new Float64Array(4096);
+    for (let i = 0; i < 4096; i++) weights[i] = cur.getBin(i) !== 0 ? Math.min(model[i] / cur.getBin(i), 1) : 0;
+    const data = [];
+    for (let x = 0; x < w; x++) {
+      const col = [];
+      for (let y = 0; y < h; y++) {
+        const p = (y * w + x) * 4;
+        col.push(weights[256 * (d[p] >> 4) + 16 * (d[p + 1] >> 4) + (d[p + 2] >> 4)]);
+      }
+      data[x] = col;
+    }
+    return data;
+  };
+
+  this.getBackProjectionImg = function () {
+    const pdf = this.getPdf();
+    const w = lastFrame.width, h = lastFrame.height;
+    const img = canvasCtx.createImageData(w, h), out = img.data;
+    for (let x = 0; x < w; x++) {
+      for (let y = 0; y < h; y++) {
+        const v = Math.floor(255 * pdf[x][y]), p = (y * w + x) * 4;
+        out[p] = v; out[p + 1] = v; out[p + 2] = v; out[p + 3] = 255;
+      }
+    }
+    return img;
+  };
+
+  this.release = function () { csPool.free.push(slot); }; /* not in the reference: returns the device slot */
+};
+
+/* ---- facetrackr ------------------------------------------------------------------------------------------------------------ */
+
+headtrackr.facetrackr = {};
+
+headtrackr.facetrackr.TrackObj = function () { /* facetrackr.js:233-255 */
+  this.height = 0; this.width = 0; this.angle = 0; this.x = 0; this.y = 0;
+  this.confidence = -10000; this.detection = ''; this.time = 0;
+  this.clone = function () {
+    const c = new headtrackr.facetrackr.TrackObj();
+    c.height = this.height; c.width = this.width; c.angle = this.angle; c.x = this.x; c.y = this.y;
+    c.confidence = this.confidence; c.detection = this.detection; c.time = this.time;
+    return c;
+  };
+};
+
+function now() { return (new Date()).getTime(); }
+
+headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
+  if (!params) params = {};
+  if (params.sendEvents === undefined) params.sendEvents = true;
+  if (params.whitebalancing === undefined) params.whitebalancing = true;
+  if (params.debug === undefined || params.debug.tagName !== 'CANVAS') params.debug = false;
+  if (params.calcAngles === undefined) params.calcAngles = false;
+  let state = params.whitebalancing ? 'WB' : 'VJ';
+  let input = null, current = null, cs = null;
+  const confidenceThreshold = -10; /* facetrackr.js:57 */
+  const wbWindow = [], wbLength = 15; /* facetrackr.js:58-59 */
+
+  this.init = function (inputcanvas) {
+    input = inputcanvas;
+    cs = new headtrackr.camshift.Tracker({ calcAngles: params.calcAngles });
+  };
+
+  function detectVJ() { /* facetrackr.js:133-182; the canvas copy + grayscale are fused into the device path */
+    const start = now();
+    const img = input.getContext('2d').getImageData(0, 0, input.width, input.height);
+    const comp = headtrackr.ccv.detect_objects_rgba(img.data, input.width, input.height, headtrackr.cascade, 5, 1);
+    const diff = now() - start;
+    let best;
+    for (let i = 0; i < comp.length; i++) if (best === undefined || comp[i].confidence > best.confidence) best = comp[i];
+    const result = new headtrackr.facetrackr.TrackObj();
+    if (best !== undefined) {
+      result.width = best.width; result.height = best.height; result.x = best.x; result.y = best.y; result.confidence = best.confidence;
+    }
+    result.time = diff;
+    result.detection = 'VJ';
+    return result;
+  }
+
+  function detectCS() { /* facetrackr.js:185-217 */
+    const start = now();
+    cs.track(input);
+    const r = cs.getTrackObj();
+    if (params.debug) params.debug.getContext('2d').putImageData(cs.getBackProjectionImg(), 0, 0);
+    const result = new headtrackr.facetrackr.TrackObj();
+    result.width = r.width; result.height = r.height; result.x = r.x; result.y = r.y; result.angle = r.angle;
+    result.confidence = 1;
+    result.time = now() - start;
+    result.detection = 'CS';
+    return result;
+  }
+
+  function checkWB() { /* facetrackr.js:220-227 */
+    const result = new headtrackr.facetrackr.TrackObj();
+    result.wb = headtrackr.getWhitebalance(input);
+    result.detection = 'WB';
+    return result;
+  }
+
+  this.track = function () { /* facetrackr.js:67-126 */
+    let result;
+    if (state === 'WB') result = checkWB();
+    else if (state === 'VJ') result = detectVJ();
+    else result = detectCS();
+
+    if (result.detection === 'WB') { /* facetrackr.js:79-95 */
+      if (wbWindow.length >= wbLength) wbWindow.pop();
+      wbWindow.unshift(result.wb);
+      if (wbWindow.length === wbLength && Math.max.apply(null, wbWindow) - Math.min.apply(null, wbWindow) < 2) state = 'VJ';
+    }
+    if (result.detection === 'VJ' && result.confidence > confidenceThreshold) { /* facetrackr.js:97-108 */
+      state = 'CS';
+      cs.initTracker(input, new headtrackr.camshift.Rectangle(Math.floor(result.x), Math.floor(result.y),
+        Math.floor(result.width), Math.floor(result.height)));
+    }
+    current = result;
+    if (result.detection === 'CS' && params.sendEvents && typeof document !== 'undefined') { /* facetrackr.js:112-125 */
+      const evt = document.createEvent('Event');
+      evt.initEvent('facetrackingEvent', true, true);
+      evt.height = result.height; evt.width = result.width; evt.angle = result.angle; evt.x = result.x; evt.y = result.y;
+      evt.confidence = result.confidence; evt.detection = result.detection; evt.time = result.time;
+      document.dispatchEvent(evt);
+    }
+  };
+
+  this.getTrackingObject = function () { return current.clone(); };
+};
+
+module.exports = headtrackr;

@@ -20,6 +20,7 @@ HT_INPUT_GRAY_IN_R = 1
 HT_SCAN_NO_SPLIT = 2
 HT_SCAN_SIMPLE = 4
 HT_SCAN_GENERIC = 8
+HT_SCAN_STATS = 16
 HT_MAX_LEVELS = 96
 
 

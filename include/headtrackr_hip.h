@@ -45,7 +45,8 @@ enum {
     HT_SCAN_FUSED_TAIL = 0, /* default scan schedule */
     HT_SCAN_NO_SPLIT = 2,   /* run every cascade stage in the tile kernel (no second "deep" kernel); debugging / A-B */
     HT_SCAN_SIMPLE = 4,     /* one thread per window straight from HBM (slow reference kernel); debugging / A-B */
-    HT_SCAN_GENERIC = 8     /* table-driven stage code even for the built-in cascade (no generated straight-line stages) */
+    HT_SCAN_GENERIC = 8,    /* table-driven stage code even for the built-in cascade (no generated straight-line stages) */
+    HT_SCAN_STATS = 16      /* also count the windows entering every stage (ht_stage_counts); costs a few atomics per workgroup */
 };
 
 typedef struct ht_config {
@@ -141,7 +142,8 @@ ht_status ht_detect_batch(ht_ctx *ctx, const uint8_t *host_rgba, int32_t n, int3
                           uint32_t *total);
 /* Test hook: copies one pyramid plane of one frame back, rows packed (width*height bytes). */
 ht_status ht_pyramid_readback(ht_ctx *ctx, int32_t frame, int32_t level, int32_t slot, uint8_t *out, size_t cap);
-/* Scan statistics of the last collected batch: windows that entered stage j, j = 0..nstages (nstages = survivors). */
+/* Scan statistics of the last collected batch (only if it was enqueued with HT_SCAN_STATS): windows that entered
+ * stage j, j = 0..nstages (nstages = full survivors). */
 ht_status ht_stage_counts(ht_ctx *ctx, uint64_t *counts, int32_t n);
 
 /* ccv.grayscale drop-in on host RGBA frames, in place (R=G=B=gray, A untouched; ccv.js:22-32). */

@@ -9,7 +9,7 @@ import pytest
 from conftest import load_golden
 from headtrackr_amd import synth
 from headtrackr_amd.api import HT_INPUT_GRAY_IN_R, HT_INPUT_RGBA, HT_SCAN_NO_SPLIT, HT_SCAN_SIMPLE, Context
-from headtrackr_amd.native import HT_SCAN_GENERIC
+from headtrackr_amd.native import HT_SCAN_GENERIC, HT_SCAN_STATS
 from oracle import ht_oracle as ho
 
 pytestmark = pytest.mark.gpu
@@ -107,7 +107,7 @@ def test_mixed_batch_hits_vs_oracle(ctx, cascade, mode):
     """N / S / F frames in one batch, every scan schedule: raw hits == oracle, in the reference's order"""
     w, h, n = 320, 240, 12
     frames = synth.mixed_batch(n, w, h, seed0=1234)
-    hits, counts = ctx.detect_raw(frames, flags=mode)
+    hits, counts = ctx.detect_raw(frames, flags=mode | HT_SCAN_STATS)
     ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(n)])
     assert_hits_equal(hits, ref)
     assert int(counts.sum()) == len(ref) and len(ref) > 0
@@ -117,6 +117,8 @@ def test_mixed_batch_hits_vs_oracle(ctx, cascade, mode):
         ho.detect_raw(frames[i], cascade.blob, stage_pass=sp)
     assert np.array_equal(ctx.stage_counts().astype(np.int64), sp)
     assert ctx.windows_per_frame * n == sp[0]
+    hits2, _ = ctx.detect_raw(frames, flags=mode)  # same results without the statistics counters
+    assert hits2.tobytes() == hits.tobytes()
 
 
 def test_gray_in_r_entry(ctx, cascade):

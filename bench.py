@@ -41,20 +41,6 @@ def parse():
     return ap.parse_args()
 
 
-def best_face_records(hits, counts, nframes):
-    """fixed-size per-frame record that is all-gathered: [count, scale, q, x, y, confidence] of the best raw hit"""
-    rec = np.zeros((nframes, 8), dtype=np.float64)
-    k = 0
-    for f in range(nframes):
-        c = int(counts[f])
-        if c:
-            h = hits[k : k + c]
-            b = h[np.argmax(h["sum"])]
-            rec[f, :6] = (c, b["scale"], b["q"], b["x"], b["y"], b["sum"])
-        k += c
-    return rec
-
-
 def main():
     a = parse()
     import torch
@@ -72,6 +58,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
+    from headtrackr_amd import distributed as hd
     from headtrackr_amd import synth
     from headtrackr_amd.api import Context
 
@@ -93,8 +80,7 @@ def main():
     if a.workload == "c3":
         ctx.camshift_reserve(nf)
 
-    rec_local = torch.zeros((nf, 8), dtype=torch.float64, device="cuda")
-    rec_all = torch.zeros((world * nf, 8), dtype=torch.float64, device="cuda") if world > 1 else None
+    rec_local = torch.zeros((nf, hd.RECORD_F64), dtype=torch.float64, device="cuda")
 
     def step():
         ctx.detect_enqueue(a.flags)
@@ -113,9 +99,9 @@ def main():
             ctx.camshift_init(rects)
             for it in range(60):
                 ctx.camshift_track(nf, calc_angles=True, fetch=(it == 59))
-        if world > 1:
-            rec_local.copy_(torch.from_numpy(best_face_records(hits, counts, nf)), non_blocking=False)
-            dist.all_gather_into_tensor(rec_all, rec_local)
+        if world > 1:  # the path's one exchange step: every rank ends up with every frame's best-face record
+            rec_local.copy_(torch.from_numpy(hd.pack_records(hits, counts, nf)), non_blocking=False)
+            hd.allgather_records(rec_local, world, nf)
         return hits, counts
 
     for _ in range(a.warmup):

@@ -1,0 +1,70 @@
+"""The N > 1 path on CPU: 2 processes, gloo backend.  Each rank produces the detection records of its block of frames
+(here with the CPU oracle standing in for the GPU — this is a test of the sharding + all-gather plumbing only), the
+records are all-gathered, and every rank must hold exactly the single-process result."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from headtrackr_amd import distributed as hd
+from headtrackr_amd import synth
+from headtrackr_amd.cascade import load_cascade
+
+N_FRAMES, W, H = 7, 160, 120
+
+
+def _records_for(frames, first):
+    from oracle import ht_oracle as ho
+
+    blob = load_cascade().blob
+    hits, counts = [], []
+    for f in frames:
+        h = ho.detect_raw(f, blob)
+        hits.append(h)
+        counts.append(len(h))
+    allh = np.concatenate(hits) if hits else np.zeros(0, dtype=ho.HIT_DTYPE)
+    return hd.pack_records(allh, np.array(counts), len(frames))
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = [synth.make(dict(family="mixed", index=i, seed0=1234), W, H) if i % 3 else synth.face_frame(W, H, [(30 + i, 20, 64)]) for i in range(N_FRAMES)]
+    a, b = hd.shard_range(N_FRAMES, rank, world)
+    maxper = max(hd.shard_range(N_FRAMES, r, world)[1] - hd.shard_range(N_FRAMES, r, world)[0] for r in range(world))
+    rec = np.zeros((maxper, hd.RECORD_F64))
+    rec[: b - a] = _records_for(frames[a:b], a)
+    gathered = hd.allgather_records(torch.from_numpy(rec), world, maxper).numpy()
+    merged = hd.unshard(gathered, N_FRAMES, world)
+    full = _records_for(frames, 0)
+    ret[rank] = bool(np.array_equal(merged, full)) and float(merged[:, 0].sum()) > 0
+    dist.destroy_process_group()
+
+
+def test_shard_ranges_cover_everything():
+    for n in (1, 7, 256, 1024):
+        for world in (1, 2, 3, 8):
+            spans = [hd.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_allgather_equals_single_process():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert ret[0] and ret[1]

@@ -383,8 +383,8 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
         uint32_t b = 0;
         for (auto &j : c->h_gens[g]) {
             j.block_begin = b;
-            j.blocks_x = (uint32_t)((j.cw + 127) / 128);
-            b += j.blocks_x * (uint32_t)((j.ch + 7) / 8);
+            j.blocks_x = (uint32_t)((j.cw + 63) / 64);   // k_resample tile: 64 x 16 destination pixels
+            b += j.blocks_x * (uint32_t)((j.ch + 15) / 16);
         }
         c->gen_blocks[g] = b;
         if (c->h_gens[g].empty()) continue;

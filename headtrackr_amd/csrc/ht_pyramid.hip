@@ -72,9 +72,39 @@ __global__ __launch_bounds__(256) void k_gray_inplace(uint8_t *__restrict__ fram
     }
 }
 
-// One generation of drawImage calls.  Block = 128 x 8 destination pixels of one job, thread = 4 pixels of a row.
+// One generation of drawImage calls.  Workgroup = RS_TW x RS_TH destination pixels of one job, thread = 4 pixels of a row.
+//   1. 64 + 16 threads compute the tile's column / row taps of the declared resampler (binary64, explicit
+//      __dmul_rn/__dadd_rn so nothing is contracted into an FMA) into LDS: a = floor(f), t = f - a, b = min(a+1, s-1);
+//   2. the source rectangle those taps touch (<= ~133 x 35 px for ratios <= 2.04) is staged into LDS with aligned dword
+//      loads, all issued before the first LDS write;
+//   3. every thread produces 4 pixels from LDS bytes: top/bot/v lerps, v_rndne_f64 (round half to even), one dword store.
+// Tiles whose source span does not fit (only the last 1-3 pixel levels, where the ratio can reach 6) read HBM directly.
+constexpr int RS_TW = 64, RS_TH = 16;        // destination tile
+constexpr int RS_SP = 160, RS_SR = 40;       // LDS source tile: bytes per row, rows
+
+struct RsTap {
+    double t, u;  // weights of b and a
+    int a, b;     // source coordinates (absolute, including the source rect origin)
+};
+
+__device__ __forceinline__ RsTap rs_tap(int i, double r, int s, int origin) {
+    double f = __dadd_rn(__dmul_rn((double)i + 0.5, r), -0.5);
+    f = f < 0.0 ? 0.0 : f;
+    const double fmax = (double)(s - 1);
+    f = f > fmax ? fmax : f;
+    const double af = floor(f);
+    RsTap tp;
+    tp.a = origin + (int)af;
+    tp.b = origin + min((int)af + 1, s - 1);
+    tp.t = __dadd_rn(f, -af);
+    tp.u = __dadd_rn(1.0, -tp.t);
+    return tp;
+}
+
 __global__ __launch_bounds__(256) void k_resample(const HtResampleJob *__restrict__ jobs, int njobs, uint8_t *__restrict__ arena,
                                                   uint64_t arena_stride) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_SR * RS_SP];
+    __shared__ RsTap s_col[RS_TW], s_row[RS_TH];
     // job lookup: block_begin is ascending; everything here is wave-uniform (scalar)
     int ji = 0;
     for (int k = 1; k < njobs; k++)
@@ -82,41 +112,72 @@ __global__ __launch_bounds__(256) void k_resample(const HtResampleJob *__restric
     const HtResampleJob &J = jobs[ji];
     const uint32_t lb = blockIdx.x - J.block_begin;
     const uint32_t by = lb / J.blocks_x, bx = lb - by * J.blocks_x;
-    const int x0 = (int)(bx * 128 + threadIdx.x * 4), y = (int)(by * 8 + threadIdx.y);
-    if (y >= J.ch || x0 >= J.dst_stride) return;
+    const int tid = (int)threadIdx.x;
+    const int X0 = (int)bx * RS_TW, Y0 = (int)by * RS_TH;
     uint8_t *frame = arena + (uint64_t)blockIdx.y * arena_stride;
     const uint8_t *src = frame + J.src_off;
+    const int ncols = min(RS_TW, J.dw - X0), nrows = min(RS_TH, J.dh - Y0);  // drawn part of this tile (may be <= 0)
+    const int x0 = X0 + (tid & 15) * 4, y = Y0 + (tid >> 4);
     uint32_t o = 0;
-    if (y < J.dh) {
-        double fy = __dadd_rn(__dmul_rn((double)y + 0.5, J.ry), -0.5);
-        fy = fy < 0.0 ? 0.0 : fy;
-        const double ymax = (double)(J.sh - 1);
-        fy = fy > ymax ? ymax : fy;
-        const double y0f = floor(fy);
-        const int y0 = (int)y0f, y1 = min(y0 + 1, J.sh - 1);
-        const double ty = __dadd_rn(fy, -y0f), uy = __dadd_rn(1.0, -ty);
-        const uint8_t *r0 = src + (size_t)(J.sy + y0) * J.src_stride + J.sx;
-        const uint8_t *r1 = src + (size_t)(J.sy + y1) * J.src_stride + J.sx;
-        const double xmax = (double)(J.sw - 1);
+    if (ncols > 0 && nrows > 0) {
+        if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
+        if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
+        __syncthreads();
+        const int xa = s_col[0].a & ~3, xb = s_col[ncols - 1].b, ya = s_row[0].a, yb = s_row[nrows - 1].b;
+        const int sw4 = (xb - xa) / 4 + 1, sh = yb - ya + 1;  // dwords per row, rows
+        const bool in_lds = (sw4 * 4 <= RS_SP) && (sh <= RS_SR);
+        if (in_lds) {
+            constexpr int KL = (RS_SR * (RS_SP / 4) + 255) / 256;
+            const int total = sh * sw4;
+            uint32_t v[KL];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int x = x0 + k;
-            if (x < J.dw) {
-                double fx = __dadd_rn(__dmul_rn((double)x + 0.5, J.rx), -0.5);
-                fx = fx < 0.0 ? 0.0 : fx;
-                fx = fx > xmax ? xmax : fx;
-                const double x0f = floor(fx);
-                const int xa = (int)x0f, xb = min(xa + 1, J.sw - 1);
-                const double tx = __dadd_rn(fx, -x0f), ux = __dadd_rn(1.0, -tx);
-                const double top = __dadd_rn(__dmul_rn((double)r0[xa], ux), __dmul_rn((double)r0[xb], tx));
-                const double bot = __dadd_rn(__dmul_rn((double)r1[xa], ux), __dmul_rn((double)r1[xb], tx));
-                const double v = __dadd_rn(__dmul_rn(top, uy), __dmul_rn(bot, ty));
-                const int q = (int)__builtin_rint(v);
-                o |= (uint32_t)min(max(q, 0), 255) << (8 * k);
+            for (int k = 0; k < KL; k++) {
+                const int i = tid + k * 256;
+                v[k] = 0;
+                if (i < total) {
+                    const int r = i / sw4, c = i - r * sw4;
+                    v[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)(ya + r) * J.src_stride + xa + 4 * c);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KL; k++) {
+                const int i = tid + k * 256;
+                if (i < total) {
+                    const int r = i / sw4, c = i - r * sw4;
+                    *reinterpret_cast<uint32_t *>(&s_src[r * RS_SP + 4 * c]) = v[k];
+                }
+            }
+            __syncthreads();
+        }
+        if (y < J.dh && x0 < J.dw) {
+            const RsTap ry = s_row[y - Y0];
+            const uint8_t *r0, *r1;
+            int xoff;
+            if (in_lds) {
+                r0 = s_src + (ry.a - ya) * RS_SP;
+                r1 = s_src + (ry.b - ya) * RS_SP;
+                xoff = xa;
+            } else {
+                r0 = src + (size_t)ry.a * J.src_stride;
+                r1 = src + (size_t)ry.b * J.src_stride;
+                xoff = 0;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (x0 + k < J.dw) {
+                    const RsTap cx = s_col[x0 + k - X0];
+                    const int ia = cx.a - xoff, ib = cx.b - xoff;
+                    const double top = __dadd_rn(__dmul_rn((double)r0[ia], cx.u), __dmul_rn((double)r0[ib], cx.t));
+                    const double bot = __dadd_rn(__dmul_rn((double)r1[ia], cx.u), __dmul_rn((double)r1[ib], cx.t));
+                    const double vv = __dadd_rn(__dmul_rn(top, ry.u), __dmul_rn(bot, ry.t));
+                    const int q = (int)__builtin_rint(vv);  // Uint8ClampedArray: round half to even
+                    o |= (uint32_t)min(max(q, 0), 255) << (8 * k);
+                }
             }
         }
     }
-    *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o;
+    // pixels outside the drawn dw x dh rect stay transparent black (ccv.js:135-145 draws 2 px short on the variants)
+    if (y < J.ch && x0 < J.dst_stride) *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o;
 }
 
 // per-frame channel sums for getWhitebalance; out[f*4 + c] (u64), zeroed by the host
@@ -174,7 +235,7 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
     for (size_t g = 1; g < c->h_gens.size(); g++) {
         if (c->gen_blocks[g] == 0) continue;
         HtProfScope ps(c, "resample");
-        hipLaunchKernelGGL(k_resample, dim3(c->gen_blocks[g], c->nframes), dim3(32, 8), 0, c->stream, c->d_gens[g],
+        hipLaunchKernelGGL(k_resample, dim3(c->gen_blocks[g], c->nframes), dim3(256), 0, c->stream, c->d_gens[g],
                            (int)c->h_gens[g].size(), c->d_arena, c->arena_stride);
         HT_HIP(c, hipGetLastError());
     }

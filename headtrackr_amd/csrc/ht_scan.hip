@@ -147,32 +147,62 @@ __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict_
     unsigned long long *my_stats = stats ? stats + (size_t)(blockIdx.x & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
 
     // ---- stage the three planes into LDS --------------------------------------------------------------------
-    {   // plane 0: level i, origin (2*X0, 2*Y0), rows of PITCH0 bytes as aligned dwords
+    // All global loads of a thread are issued before the first LDS write (fixed trip counts, predicated), so one
+    // memory latency is paid per tile instead of one per loop iteration; everything is loaded as aligned dwords /
+    // halfwords (tile origins are multiples of 4 half-steps).
+    {
+        // plane 0: level i, origin (2*X0, 2*Y0), PITCH0 bytes per row
         const uint8_t *p0 = fbase + L0.off[0];
         const int gx0 = 2 * X0, gy0 = 2 * Y0;
-        const int rows = 2 * th + 22;
-        for (int i = (int)tid; i < rows * (PITCH0 / 4); i += NT) {
+        const int n0 = (2 * th + 22) * (PITCH0 / 4);
+        constexpr int K0 = (ROWS0 * (PITCH0 / 4) + NT - 1) / NT;
+        uint32_t v0[K0];
+#pragma unroll
+        for (int k = 0; k < K0; k++) {
+            const int i = (int)tid + k * NT;
             const int r = i / (PITCH0 / 4), c4 = (i - r * (PITCH0 / 4)) * 4;
             const int gy = gy0 + r, gx = gx0 + c4;
-            uint32_t v = 0;
-            if (gy < L0.h && gx < L0.stride) v = *reinterpret_cast<const uint32_t *>(p0 + (size_t)gy * L0.stride + gx);
-            *reinterpret_cast<uint32_t *>(&lds[r * PITCH0 + c4]) = v;
+            v0[k] = 0;
+            if (i < n0 && gy < L0.h && gx < L0.stride) v0[k] = *reinterpret_cast<const uint32_t *>(p0 + (size_t)gy * L0.stride + gx);
         }
         // planes 1 + 2: half-step grid cell (X, Y) = { level i+6 pixel (X0+X, Y0+Y),  variant q pixel ((X0+X)>>1, (Y0+Y)>>1) }
-        // with q = ((Y0+Y)&1)*2 + ((X0+X)&1)   (ccv.js:132-146: variant q is level i+6 shifted by (dx,dy) then halved)
+        // with q = ((Y0+Y)&1)*2 + ((X0+X)&1)   (ccv.js:132-146: variant q is level i+6 shifted by (dx,dy) then halved).
+        // A thread builds 4 consecutive cells from one dword of level i+6 and one halfword of each of the two variants.
         const uint8_t *p1 = fbase + L1.off[0];
-        const int gw = tw + 11, gh = th + 11;
-        for (int Y = (int)(tid >> 6); Y < gh; Y += NT / 64) {
-            const int ay = Y0 + Y;
-            const int y2 = ay >> 1;
-            for (int X = (int)lane; X < gw; X += 64) {
-                const int ax = X0 + X;
-                const int q = ((ay & 1) << 1) | (ax & 1), x2 = ax >> 1;
-                uint32_t a = 0, b = 0;
-                if (ay < L1.h && ax < L1.w) a = p1[(size_t)ay * L1.stride + ax];
-                const uint32_t o2 = q == 0 ? L2.off[0] : (q == 1 ? L2.off[1] : (q == 2 ? L2.off[2] : L2.off[3]));
-                if (y2 < L2.h && x2 < L2.w) b = fbase[o2 + (size_t)y2 * L2.stride + x2];
-                *reinterpret_cast<uint16_t *>(&lds[P12_BASE + Y * G_PITCH + 2 * X]) = (uint16_t)(a | (b << 8));
+        constexpr int GG = (TXH + 11 + 3) / 4;  // cell groups per row (19)
+        const int n12 = (th + 11) * GG;
+        constexpr int K12 = (GH * GG + NT - 1) / NT;
+        uint32_t va[K12], vb[K12], vc[K12];
+#pragma unroll
+        for (int k = 0; k < K12; k++) {
+            const int g = (int)tid + k * NT;
+            const int Y = g / GG, Xg = (g - Y * GG) * 4;
+            const int ay = Y0 + Y, ax = X0 + Xg, y2 = ay >> 1, x2 = ax >> 1;
+            const uint32_t o2a = (ay & 1) ? L2.off[2] : L2.off[0], o2b = (ay & 1) ? L2.off[3] : L2.off[1];
+            va[k] = vb[k] = vc[k] = 0;
+            if (g < n12) {
+                if (ay < L1.h && ax < L1.stride) va[k] = *reinterpret_cast<const uint32_t *>(p1 + (size_t)ay * L1.stride + ax);
+                if (y2 < L2.h && x2 < L2.stride) {
+                    vb[k] = *reinterpret_cast<const uint16_t *>(fbase + o2a + (size_t)y2 * L2.stride + x2);
+                    vc[k] = *reinterpret_cast<const uint16_t *>(fbase + o2b + (size_t)y2 * L2.stride + x2);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < K0; k++) {
+            const int i = (int)tid + k * NT;
+            if (i < n0) *reinterpret_cast<uint32_t *>(&lds[i * 4]) = v0[k];  // rows are contiguous: r*PITCH0 + c4 == i*4
+        }
+#pragma unroll
+        for (int k = 0; k < K12; k++) {
+            const int g = (int)tid + k * NT;
+            if (g < n12) {
+                const int Y = g / GG, Xg = (g - Y * GG) * 4;
+                const uint32_t a = va[k], b = vb[k], c = vc[k];
+                uint2 w;
+                w.x = (a & 0xffu) | ((b & 0xffu) << 8) | ((a & 0xff00u) << 8) | ((c & 0xffu) << 24);
+                w.y = ((a >> 16) & 0xffu) | (b & 0xff00u) | ((a >> 8) & 0xff0000u) | ((c & 0xff00u) << 16);
+                *reinterpret_cast<uint2 *>(&lds[P12_BASE + Y * G_PITCH + 2 * Xg]) = w;
             }
         }
     }
@@ -589,7 +619,7 @@ ht_status ht_scan_plan_tiles(ht_ctx *c) {
         if (S.qw <= 0 || S.qh <= 0) continue;
         S.ntx = (2 * S.qw + TXH - 1) / TXH;
         S.tw2 = (2 * S.qw + S.ntx - 1) / S.ntx;
-        S.tw2 += S.tw2 & 1;  // even, so plane-0 tile rows start on a dword
+        S.tw2 = (S.tw2 + 3) & ~3;  // multiple of 4 half-steps: every tile row starts on a dword in all three planes
         S.nty = (2 * S.qh + TYH - 1) / TYH;
         S.th2 = (2 * S.qh + S.nty - 1) / S.nty;
         S.th2 += S.th2 & 1;

@@ -1,0 +1,27 @@
+#!/bin/bash
+# tools/gpu_pmc.sh — rocprofv3 PMC passes (counters only + kernel trace, one counter set per run) for bench.py
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
+export TMPDIR=/tmp
+WL=${PMC_WL:-c2}
+cd /tmp
+i=0
+for set in "${@:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY}"; do
+  i=$((i+1))
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_${WL}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --cpu-seconds 0 > $OUT/pmc_${WL}_$i.log 2>&1
+  echo "set $i: $set -> exit $?"
+  python - <<PY
+import csv,glob,collections
+fs=glob.glob("$OUT/pmc_${WL}_$i/**/*counter_collection.csv", recursive=True)
+if not fs: print("no counter csv"); raise SystemExit
+agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
+for r in csv.DictReader(open(fs[0])):
+    k=r["Kernel_Name"].split("(")[0][-40:]
+    agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); 
+    if r["Counter_Name"]=="$(echo $set | cut -d' ' -f1)": cnt[k]+=1
+for k,v in agg.items():
+    n=max(cnt[k],1)
+    print(k, "launches",n, {c: round(x/n) for c,x in v.items()})
+PY
+done
+find $OUT -name "*kernel_trace.csv" -size +1M -delete; find $OUT -name "*counter_collection.csv" -size +4M -delete

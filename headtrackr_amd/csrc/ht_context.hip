@@ -7,6 +7,7 @@
 //   grouping            ccv.js:34-107 (array_group), 249-332 (averaging, nested-rect filter)
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -212,6 +213,10 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         }
         c->own_stream = true;
     }
+    if (const char *e = getenv("HT_DEBUG_RS_RPT")) {  // measurement knob
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4) c->rs_rpt = v;
+    }
     c->split_stage = std::min<uint32_t>(4, c->nstages);
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     if ((st = upload_cascade(c)) != HT_OK) return bail(st);
@@ -232,6 +237,10 @@ static void free_geometry(ht_ctx *c) {
     if (c->d_queue) (void)hipFree(c->d_queue), c->d_queue = nullptr;
     for (auto p : c->d_gens)
         if (p) (void)hipFree(p);
+    for (auto p : c->d_gen_blocks)
+        if (p) (void)hipFree(p);
+    c->d_gen_blocks.clear();
+    if (c->d_tile_refs) (void)hipFree(c->d_tile_refs), c->d_tile_refs = nullptr;
     c->d_gens.clear();
     c->h_gens.clear();
     c->gen_blocks.clear();
@@ -378,16 +387,27 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
         }
     }
     c->d_gens.assign(ngen, nullptr);
+    c->d_gen_blocks.assign(ngen, nullptr);
     c->gen_blocks.assign(ngen, 0);
     for (int g = 1; g < ngen; g++) {
         uint32_t b = 0;
         for (auto &j : c->h_gens[g]) {
             j.block_begin = b;
-            j.blocks_x = (uint32_t)((j.cw + 63) / 64);   // k_resample tile: 64 x 16 destination pixels
-            b += j.blocks_x * (uint32_t)((j.ch + 15) / 16);
+            j.blocks_x = (uint32_t)((j.cw + 63) / 64);   // k_resample tile: 64 x (16 * rs_rpt) destination pixels
+            b += j.blocks_x * (uint32_t)((j.ch + 16 * c->rs_rpt - 1) / (16 * c->rs_rpt));
         }
         c->gen_blocks[g] = b;
         if (c->h_gens[g].empty()) continue;
+        std::vector<HtBlockRef> refs;
+        refs.reserve(b);
+        for (size_t ji = 0; ji < c->h_gens[g].size(); ji++) {
+            const HtResampleJob &j = c->h_gens[g][ji];
+            const uint32_t nby = (uint32_t)((j.ch + 16 * c->rs_rpt - 1) / (16 * c->rs_rpt));
+            for (uint32_t y = 0; y < nby; y++)
+                for (uint32_t x = 0; x < j.blocks_x; x++) refs.push_back(HtBlockRef{(uint16_t)ji, (uint16_t)x, (uint16_t)y, 0});
+        }
+        HT_HIP(c, hipMalloc(&c->d_gen_blocks[g], refs.size() * sizeof(HtBlockRef)));
+        HT_HIP(c, hipMemcpy(c->d_gen_blocks[g], refs.data(), refs.size() * sizeof(HtBlockRef), hipMemcpyHostToDevice));
         HT_HIP(c, hipMalloc(&c->d_gens[g], c->h_gens[g].size() * sizeof(HtResampleJob)));
         HT_HIP(c, hipMemcpy(c->d_gens[g], c->h_gens[g].data(), c->h_gens[g].size() * sizeof(HtResampleJob), hipMemcpyHostToDevice));
     }

@@ -95,6 +95,13 @@ struct HtScanScale {
     uint32_t win_begin;   // first window of this scale in the flat per-frame window index (simple kernel)
 };
 
+// Direct block -> work lookup (one 8-byte load per workgroup instead of a serial scan over a prefix table).
+struct HtBlockRef {
+    uint16_t item;  // resample: job index in the generation; scan: index into the scale table
+    uint16_t bx, by;
+    uint16_t pad;
+};
+
 // Survivor handed from the tile kernel to the deep kernel.
 struct HtQueueEntry {
     uint32_t frame;
@@ -159,10 +166,13 @@ struct ht_ctx {
     uint8_t *d_arena = nullptr;
     std::vector<std::vector<HtResampleJob>> h_gens;  // generation g: jobs that only depend on generations < g
     std::vector<HtResampleJob *> d_gens;
+    std::vector<HtBlockRef *> d_gen_blocks;  // per generation: block -> (job, bx, by)
+    HtBlockRef *d_tile_refs = nullptr;        // per-frame tile -> (scale, tx, ty)
     std::vector<uint32_t> gen_blocks;
     std::vector<HtScanScale> h_scales;
     HtScanScale *d_scales = nullptr;
     uint32_t tiles_per_frame = 0;
+    int rs_rpt = 2;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
 
     // frames
     uint8_t *d_frames_own = nullptr;

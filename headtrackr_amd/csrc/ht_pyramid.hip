@@ -79,8 +79,11 @@ __global__ __launch_bounds__(256) void k_gray_inplace(uint8_t *__restrict__ fram
 //      loads, all issued before the first LDS write;
 //   3. every thread produces 4 pixels from LDS bytes: top/bot/v lerps, v_rndne_f64 (round half to even), one dword store.
 // Tiles whose source span does not fit (only the last 1-3 pixel levels, where the ratio can reach 6) read HBM directly.
-constexpr int RS_TW = 64, RS_TH = 16;        // destination tile
-constexpr int RS_SP = 160, RS_SR = 40;       // LDS source tile: bytes per row, rows
+constexpr int RS_TW = 64;                   // destination tile width; its height is 16 * RPT (RPT rows per thread)
+constexpr int RS_SP = 160;                  // LDS source tile: bytes per row (64 * 2.04 + 2, dword aligned start)
+// A workgroup's latency chain (taps -> barrier -> HBM loads -> barrier -> LDS reads -> store) is fixed, so the tile
+// height decides how much of it is amortised: with 16 rows (1 row per thread) the 260k waves of one C2 generation run
+// in ~32 occupancy rounds of ~4 us each.
 
 struct RsTap {
     double t, u;  // weights of b and a
@@ -101,83 +104,95 @@ __device__ __forceinline__ RsTap rs_tap(int i, double r, int s, int origin) {
     return tp;
 }
 
-__global__ __launch_bounds__(256) void k_resample(const HtResampleJob *__restrict__ jobs, int njobs, uint8_t *__restrict__ arena,
-                                                  uint64_t arena_stride) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[RS_SR * RS_SP];
-    __shared__ RsTap s_col[RS_TW], s_row[RS_TH];
-    // job lookup: block_begin is ascending; everything here is wave-uniform (scalar)
-    int ji = 0;
-    for (int k = 1; k < njobs; k++)
-        if (blockIdx.x >= jobs[k].block_begin) ji = k;
-    const HtResampleJob &J = jobs[ji];
-    const uint32_t lb = blockIdx.x - J.block_begin;
-    const uint32_t by = lb / J.blocks_x, bx = lb - by * J.blocks_x;
+// 4 destination pixels of one row from two source rows (r0/r1 either in LDS or in HBM: two instantiations, so the loads
+// are ds_read_u8 / global_load_ubyte rather than flat loads)
+template <typename PTR>
+__device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap *s_col, const RsTap &ry, int cbase, int xoff, int npx) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k < npx) {
+            const RsTap cx = s_col[cbase + k];
+            const int ia = cx.a - xoff, ib = cx.b - xoff;
+            const double top = __dadd_rn(__dmul_rn((double)r0[ia], cx.u), __dmul_rn((double)r0[ib], cx.t));
+            const double bot = __dadd_rn(__dmul_rn((double)r1[ia], cx.u), __dmul_rn((double)r1[ib], cx.t));
+            const double vv = __dadd_rn(__dmul_rn(top, ry.u), __dmul_rn(bot, ry.t));
+            const int q = (int)__builtin_rint(vv);  // Uint8ClampedArray: round half to even (values are within [0,255])
+            o |= (uint32_t)q << (8 * k);
+        }
+    }
+    return o;
+}
+
+template <int RPT>
+__global__ __launch_bounds__(256) void k_resample(const HtResampleJob *__restrict__ jobs, const HtBlockRef *__restrict__ refs,
+                                                  uint8_t *__restrict__ arena, uint64_t arena_stride) {
+    constexpr int TH = 16 * RPT;               // destination rows per tile
+    constexpr int SR = 2 * TH + TH / 16 + 6;   // LDS source rows (ratio <= 2.04 plus the tap pair)
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[SR * RS_SP];
+    __shared__ RsTap s_col[RS_TW], s_row[TH];
+    const HtBlockRef ref = refs[blockIdx.x];  // block -> (job, tile x, tile y): one scalar load
+    const HtResampleJob &J = jobs[ref.item];
     const int tid = (int)threadIdx.x;
-    const int X0 = (int)bx * RS_TW, Y0 = (int)by * RS_TH;
+    const int X0 = (int)ref.bx * RS_TW, Y0 = (int)ref.by * TH;
     uint8_t *frame = arena + (uint64_t)blockIdx.y * arena_stride;
     const uint8_t *src = frame + J.src_off;
-    const int ncols = min(RS_TW, J.dw - X0), nrows = min(RS_TH, J.dh - Y0);  // drawn part of this tile (may be <= 0)
-    const int x0 = X0 + (tid & 15) * 4, y = Y0 + (tid >> 4);
-    uint32_t o = 0;
+    const int ncols = min(RS_TW, J.dw - X0), nrows = min(TH, J.dh - Y0);  // drawn part of this tile (may be <= 0)
+    const int x0 = X0 + (tid & 15) * 4, yt = Y0 + (tid >> 4);              // this thread: rows yt, yt+16, ...
+    uint32_t o[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; q++) o[q] = 0;
     if (ncols > 0 && nrows > 0) {
         if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
         if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
         __syncthreads();
         const int xa = s_col[0].a & ~3, xb = s_col[ncols - 1].b, ya = s_row[0].a, yb = s_row[nrows - 1].b;
         const int sw4 = (xb - xa) / 4 + 1, sh = yb - ya + 1;  // dwords per row, rows
-        const bool in_lds = (sw4 * 4 <= RS_SP) && (sh <= RS_SR);
+        const bool in_lds = (sw4 * 4 <= RS_SP) && (sh <= SR);
+        const int npx = min(4, J.dw - x0);
         if (in_lds) {
-            constexpr int KL = (RS_SR * (RS_SP / 4) + 255) / 256;
-            const int total = sh * sw4;
+            // source rows as aligned dwords, fixed 40-dword pitch so the index split is a constant division; all loads
+            // are issued before the first LDS write
+            constexpr int RW = RS_SP / 4, KL = (SR * RW + 255) / 256;
+            const uint8_t *sbase = src + (size_t)ya * J.src_stride + xa;
             uint32_t v[KL];
 #pragma unroll
             for (int k = 0; k < KL; k++) {
-                const int i = tid + k * 256;
+                const int i = tid + k * 256, r = i / RW, c = i - r * RW;
                 v[k] = 0;
-                if (i < total) {
-                    const int r = i / sw4, c = i - r * sw4;
-                    v[k] = *reinterpret_cast<const uint32_t *>(src + (size_t)(ya + r) * J.src_stride + xa + 4 * c);
-                }
+                if (r < sh && c < sw4) v[k] = *reinterpret_cast<const uint32_t *>(sbase + (size_t)r * J.src_stride + 4 * c);
             }
 #pragma unroll
             for (int k = 0; k < KL; k++) {
                 const int i = tid + k * 256;
-                if (i < total) {
-                    const int r = i / sw4, c = i - r * sw4;
-                    *reinterpret_cast<uint32_t *>(&s_src[r * RS_SP + 4 * c]) = v[k];
-                }
+                if (i < SR * RW) *reinterpret_cast<uint32_t *>(&s_src[i * 4]) = v[k];
             }
             __syncthreads();
-        }
-        if (y < J.dh && x0 < J.dw) {
-            const RsTap ry = s_row[y - Y0];
-            const uint8_t *r0, *r1;
-            int xoff;
-            if (in_lds) {
-                r0 = s_src + (ry.a - ya) * RS_SP;
-                r1 = s_src + (ry.b - ya) * RS_SP;
-                xoff = xa;
-            } else {
-                r0 = src + (size_t)ry.a * J.src_stride;
-                r1 = src + (size_t)ry.b * J.src_stride;
-                xoff = 0;
-            }
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (x0 + k < J.dw) {
-                    const RsTap cx = s_col[x0 + k - X0];
-                    const int ia = cx.a - xoff, ib = cx.b - xoff;
-                    const double top = __dadd_rn(__dmul_rn((double)r0[ia], cx.u), __dmul_rn((double)r0[ib], cx.t));
-                    const double bot = __dadd_rn(__dmul_rn((double)r1[ia], cx.u), __dmul_rn((double)r1[ib], cx.t));
-                    const double vv = __dadd_rn(__dmul_rn(top, ry.u), __dmul_rn(bot, ry.t));
-                    const int q = (int)__builtin_rint(vv);  // Uint8ClampedArray: round half to even
-                    o |= (uint32_t)min(max(q, 0), 255) << (8 * k);
+            for (int q = 0; q < RPT; q++) {
+                const int y = yt + 16 * q;
+                if (y < J.dh && npx > 0) {
+                    const RsTap ry = s_row[y - Y0];
+                    o[q] = rs_pixels4<const uint8_t *>(s_src + (ry.a - ya) * RS_SP, s_src + (ry.b - ya) * RS_SP, s_col, ry, x0 - X0, xa, npx);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < RPT; q++) {
+                const int y = yt + 16 * q;
+                if (y < J.dh && npx > 0) {
+                    const RsTap ry = s_row[y - Y0];
+                    o[q] = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * J.src_stride, src + (size_t)ry.b * J.src_stride, s_col, ry, x0 - X0, 0, npx);
                 }
             }
         }
     }
     // pixels outside the drawn dw x dh rect stay transparent black (ccv.js:135-145 draws 2 px short on the variants)
-    if (y < J.ch && x0 < J.dst_stride) *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o;
+#pragma unroll
+    for (int q = 0; q < RPT; q++) {
+        const int y = yt + 16 * q;
+        if (y < J.ch && x0 < J.dst_stride) *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o[q];
+    }
 }
 
 // per-frame channel sums for getWhitebalance; out[f*4 + c] (u64), zeroed by the host
@@ -235,8 +250,15 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
     for (size_t g = 1; g < c->h_gens.size(); g++) {
         if (c->gen_blocks[g] == 0) continue;
         HtProfScope ps(c, "resample");
-        hipLaunchKernelGGL(k_resample, dim3(c->gen_blocks[g], c->nframes), dim3(256), 0, c->stream, c->d_gens[g],
-                           (int)c->h_gens[g].size(), c->d_arena, c->arena_stride);
+        if (c->rs_rpt == 4)
+            hipLaunchKernelGGL(k_resample<4>, dim3(c->gen_blocks[g], c->nframes), dim3(256), 0, c->stream, c->d_gens[g],
+                               c->d_gen_blocks[g], c->d_arena, c->arena_stride);
+        else if (c->rs_rpt == 2)
+            hipLaunchKernelGGL(k_resample<2>, dim3(c->gen_blocks[g], c->nframes), dim3(256), 0, c->stream, c->d_gens[g],
+                               c->d_gen_blocks[g], c->d_arena, c->arena_stride);
+        else
+            hipLaunchKernelGGL(k_resample<1>, dim3(c->gen_blocks[g], c->nframes), dim3(256), 0, c->stream, c->d_gens[g],
+                               c->d_gen_blocks[g], c->d_arena, c->arena_stride);
         HT_HIP(c, hipGetLastError());
     }
     return HT_OK;

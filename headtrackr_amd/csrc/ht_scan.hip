@@ -116,7 +116,7 @@ __device__ __forceinline__ double eval_stage_lds(const uint8_t *lds, uint32_t B,
 template <bool GEN>
 __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                    const HtDevLevel *__restrict__ levels, const HtScanScale *__restrict__ scales,
-                                                   int nscales, const HtTileFeature *__restrict__ feats,
+                                                   const HtBlockRef *__restrict__ tile_refs, const HtTileFeature *__restrict__ feats,
                                                    const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,
                                                    int stop_stage, uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
                                                    uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
@@ -131,12 +131,9 @@ __global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict_
     const uint32_t t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
     if (t >= total_tiles) return;
     const uint32_t frame = t / tiles_per_frame, lt = t - frame * tiles_per_frame;
-    int si = 0;
-    for (int k = 1; k < nscales; k++)
-        if (lt >= scales[k].tile_begin) si = k;
-    const HtScanScale S = scales[si];
-    const uint32_t tl = lt - S.tile_begin;
-    const int tyi = (int)(tl / (uint32_t)S.ntx), txi = (int)(tl - (uint32_t)tyi * S.ntx);
+    const HtBlockRef ref = tile_refs[lt];  // tile -> (scale, tile x, tile y): one scalar load
+    const HtScanScale S = scales[ref.item];
+    const int tyi = (int)ref.by, txi = (int)ref.bx;
     const int X0 = txi * S.tw2, Y0 = tyi * S.th2;           // tile origin in half-window steps
     const int tw = min(S.tw2, 2 * S.qw - X0), th = min(S.th2, 2 * S.qh - Y0);
     const HtDevLevel L0 = levels[S.l0], L1 = levels[S.l1], L2 = levels[S.l2];
@@ -635,6 +632,12 @@ ht_status ht_scan_plan_tiles(ht_ctx *c) {
     }
     c->tiles_per_frame = tiles;
     if (!c->h_scales.empty()) {
+        std::vector<HtBlockRef> refs;
+        for (size_t si = 0; si < c->h_scales.size(); si++)
+            for (int y = 0; y < c->h_scales[si].nty; y++)
+                for (int x = 0; x < c->h_scales[si].ntx; x++) refs.push_back(HtBlockRef{(uint16_t)si, (uint16_t)x, (uint16_t)y, 0});
+        HT_HIP(c, hipMalloc(&c->d_tile_refs, refs.size() * sizeof(HtBlockRef)));
+        HT_HIP(c, hipMemcpy(c->d_tile_refs, refs.data(), refs.size() * sizeof(HtBlockRef), hipMemcpyHostToDevice));
         HT_HIP(c, hipMalloc(&c->d_scales, c->h_scales.size() * sizeof(HtScanScale)));
         HT_HIP(c, hipMemcpy(c->d_scales, c->h_scales.data(), c->h_scales.size() * sizeof(HtScanScale), hipMemcpyHostToDevice));
     }
@@ -668,11 +671,11 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
         HtProfScope ps(c, "scan_tiles");
         if (gen)
             hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                               c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, c->tiles_per_frame,
+                               c->d_scales, c->d_tile_refs, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, c->tiles_per_frame,
                                total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
         else
             hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                               c->d_scales, nscales, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, c->tiles_per_frame,
+                               c->d_scales, c->d_tile_refs, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, c->tiles_per_frame,
                                total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
         HT_HIP(c, hipGetLastError());
     }

@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
+    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn")
     return ap.parse_args()
 
 
@@ -73,18 +74,45 @@ def main():
     base = synth.mixed_batch(uniq, W, H, seed0=1234 + 1000 * rank)
     frames = base[np.arange(nf) % uniq]
     dev = torch.from_numpy(frames).cuda()  # resident in HBM before the timed region
-    stream = torch.cuda.current_stream()
-    ctx = Context(device=local, stream=stream.cuda_stream)
-    ctx.set_geometry(W, H, nf)
-    ctx.bind_device(dev.data_ptr(), nf, W * H * 4)
+    # every step is one full pass over the batch with its results collected on the host; with --pipeline 2 the next
+    # step is enqueued (on a second context / HIP stream) before the previous one is collected, so the host-side
+    # collect + sort of step i overlaps the GPU work of step i+1.  All K steps are collected inside the timed region.
+    depth = 1 if a.workload == "c3" else max(1, a.pipeline)
+    ctxs = []
+    for _ in range(depth):
+        cx = Context(device=local)
+        cx.set_geometry(W, H, nf)
+        cx.bind_device(dev.data_ptr(), nf, W * H * 4)
+        ctxs.append(cx)
+    ctx = ctxs[0]
     if a.workload == "c3":
         ctx.camshift_reserve(nf)
 
     rec_local = torch.zeros((nf, hd.RECORD_F64), dtype=torch.float64, device="cuda")
 
+    def finish(cx):
+        hits, counts = cx.detect_collect(cap=1 << 16)
+        if world > 1:  # the path's one exchange step: every rank ends up with every frame's best-face record
+            rec_local.copy_(torch.from_numpy(hd.pack_records(hits, counts, nf)), non_blocking=False)
+            hd.allgather_records(rec_local, world, nf)
+        return hits, counts
+
+    def run_steps(k):
+        inflight = []
+        last = None
+        for i in range(k):
+            cx = ctxs[i % depth]
+            if len(inflight) == depth:
+                last = finish(inflight.pop(0))
+            cx.detect_enqueue(a.flags)
+            inflight.append(cx)
+        while inflight:
+            last = finish(inflight.pop(0))
+        return last
+
     def step():
         ctx.detect_enqueue(a.flags)
-        hits, counts = ctx.detect_collect(cap=1 << 18)
+        hits, counts = ctx.detect_collect(cap=1 << 16)
         if a.workload == "c3":
             # detect once, then 60 camshift track() calls on the (static) batch, SURVEY.md §8 C3
             starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
@@ -104,8 +132,11 @@ def main():
             hd.allgather_records(rec_local, world, nf)
         return hits, counts
 
-    for _ in range(a.warmup):
-        hits, counts = step()
+    if a.workload == "c3":
+        for _ in range(a.warmup):
+            hits, counts = step()
+    else:
+        hits, counts = run_steps(max(a.warmup, depth))
 
     def fence():
         if world > 1:
@@ -114,8 +145,11 @@ def main():
 
     fence()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        hits, counts = step()
+    if a.workload == "c3":
+        for _ in range(a.steps):
+            hits, counts = step()
+    else:
+        hits, counts = run_steps(a.steps)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -134,7 +168,7 @@ def main():
         psteps = max(3, min(10, a.steps))
         for _ in range(psteps):
             ctx.detect_enqueue(a.flags)
-            ctx.detect_collect(cap=1 << 18)
+            ctx.detect_collect(cap=1 << 16)
         kt = ctx.kernel_times(reset=True)
         ctx.profile(False)
         per_step = {k: v["ms"] / psteps for k, v in kt.items()}
@@ -156,7 +190,7 @@ def main():
                         algorithmic_bytes_per_frame=b_detect, avg_launch_ms=round(avg_launch_ms, 5))
         dev_ms = sum(per_step.values())
         ctx.detect_enqueue(a.flags | 16)  # one extra untimed pass with HT_SCAN_STATS for the survival curve
-        ctx.detect_collect(cap=1 << 18)
+        ctx.detect_collect(cap=1 << 16)
         sc = ctx.stage_counts()
         extra = dict(kernel_ms_per_step={k: round(v, 5) for k, v in per_step.items()},
                      device_ms_per_step=round(dev_ms, 5),
@@ -192,13 +226,14 @@ def main():
             "config": {"workload": {"c2": "C2: 256 x 320x240 RGBA frames per GPU, full BBF cascade detect (interval 5), raw hits to host",
                                     "c3": "C3: 256 x 320x240 per GPU, detect once then 60 camshift track() calls",
                                     "c4": "C4: 1280x720 frames, 128 per GPU (1024 on 8 GPUs), full cascade detect + all-gather of best-face records"}[a.workload],
-                       "frames_per_gpu": nf, "width": W, "height": H, "unique_frames": uniq, "frame_mix": "1/3 LCG noise, 1/3 smooth, 1/3 faces",
+                       "frames_per_gpu": nf, "batches_in_flight": depth, "width": W, "height": H, "unique_frames": uniq, "frame_mix": "1/3 LCG noise, 1/3 smooth, 1/3 faces",
                        "parallelism": f"frames sharded over {world} GPU(s), all-gather of {nf}x64B records" if world > 1 else "1 GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)
-    ctx.close()
+    for cx in ctxs:
+        cx.close()
     if world > 1:
         dist.destroy_process_group()
 

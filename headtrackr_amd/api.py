@@ -97,11 +97,13 @@ class Context:
         self._check(self._lib.ht_detect_enqueue(self._h, flags))
 
     def detect_collect(self, cap: int = 1 << 16):
-        hits = np.zeros(cap, dtype=HIT_DTYPE)
-        counts = np.zeros(max(1, self.nframes), dtype=np.uint32)
+        buf = getattr(self, "_hitbuf", None)
+        if buf is None or len(buf) < cap:
+            buf = self._hitbuf = np.empty(cap, dtype=HIT_DTYPE)  # reused across calls
+        counts = np.empty(max(1, self.nframes), dtype=np.uint32)
         total = C.c_uint32(0)
-        self._check(self._lib.ht_detect_collect(self._h, hits.ctypes.data, cap, counts.ctypes.data, C.byref(total)))
-        return hits[: total.value].copy(), counts[: self.nframes]
+        self._check(self._lib.ht_detect_collect(self._h, buf.ctypes.data, cap, counts.ctypes.data, C.byref(total)))
+        return buf[: total.value].copy(), counts[: self.nframes]
 
     def detect_raw(self, frames: np.ndarray, flags: int = HT_INPUT_RGBA, cap: int = 1 << 16):
         """ccv.grayscale + ccv.detect_objects(..., min_neighbors = 0) for a batch: (hits, per-frame counts)."""

@@ -217,10 +217,12 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4) c->rs_rpt = v;
     }
-    c->split_stage = std::min<uint32_t>(4, c->nstages);
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
+    // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
+    c->split_stage = std::min<uint32_t>(c->builtin_cascade ? 8u : 4u, c->nstages);
     if ((st = upload_cascade(c)) != HT_OK) return bail(st);
-    if (hipMalloc(&c->d_stats, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS) != hipSuccess ||
+    if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), sizeof(HtCounters) + (size_t)HT_PINNED_HITS * sizeof(ht_hit), hipHostMallocDefault) != hipSuccess ||
+        hipMalloc(&c->d_stats, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS) != hipSuccess ||
         hipMalloc(&c->d_counters, sizeof(HtCounters)) != hipSuccess ||
         hipMalloc(&c->d_hits, (size_t)c->hit_capacity * sizeof(ht_hit)) != hipSuccess) {
         c->err = "hipMalloc(hits) failed";
@@ -260,6 +262,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_hits) (void)hipFree(c->d_hits);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_cs) (void)hipFree(c->d_cs);
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
@@ -520,8 +523,12 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
     if (!c) return HT_ERR_INVALID;
     if (!c->enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_collect: nothing enqueued");
     HT_HIP(c, hipSetDevice(c->device));
-    HT_HIP(c, hipMemcpyAsync(&c->h_counters, c->d_counters, sizeof(HtCounters), hipMemcpyDeviceToHost, c->stream));
+    // counters + the first HT_PINNED_HITS hits in one go (pinned host memory), one synchronisation per batch
+    const uint32_t spec = std::min<uint32_t>(HT_PINNED_HITS, c->hit_capacity);
+    HT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_counters, sizeof(HtCounters), hipMemcpyDeviceToHost, c->stream));
+    HT_HIP(c, hipMemcpyAsync(c->h_pinned + sizeof(HtCounters), c->d_hits, (size_t)spec * sizeof(ht_hit), hipMemcpyDeviceToHost, c->stream));
     HT_HIP(c, hipStreamSynchronize(c->stream));
+    std::memcpy(&c->h_counters, c->h_pinned, sizeof(HtCounters));
     c->enqueued = false;
     std::memset(c->h_stage_in, 0, sizeof(c->h_stage_in));
     if (c->stats_enqueued) {
@@ -537,7 +544,10 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
         return ht_fail(c, HT_ERR_CAPACITY, "ht_detect_collect: more raw hits than ht_config.hit_capacity; results incomplete");
     std::vector<ht_hit> tmp(found);
     if (found) {
-        HT_HIP(c, hipMemcpy(tmp.data(), c->d_hits, (size_t)found * sizeof(ht_hit), hipMemcpyDeviceToHost));
+        const uint32_t have = std::min(found, spec);
+        std::memcpy(tmp.data(), c->h_pinned + sizeof(HtCounters), (size_t)have * sizeof(ht_hit));
+        if (found > have)
+            HT_HIP(c, hipMemcpy(tmp.data() + have, c->d_hits + have, (size_t)(found - have) * sizeof(ht_hit), hipMemcpyDeviceToHost));
         std::sort(tmp.begin(), tmp.end(), hit_less);
     }
     if (counts)

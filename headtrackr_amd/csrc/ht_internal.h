@@ -112,6 +112,7 @@ struct HtQueueEntry {
 };
 static_assert(sizeof(HtQueueEntry) == 16, "HtQueueEntry");
 
+#define HT_PINNED_HITS 8192
 #define HT_STAT_SHARDS 256  // rows of 64 u64 counters; a workgroup adds to row (blockIdx & 255)
 
 // Device counters block (zeroed before each batch).
@@ -153,7 +154,8 @@ struct ht_ctx {
     HtDeepFeature *d_deep_feats = nullptr;
     HtPatchFeature *d_patch_feats = nullptr;
     bool builtin_cascade = false;  // blob == the cascade ht_cascade_gen.inc was generated from
-    uint32_t deep_bias = 3;        // tile kernel hands survivors to the deep kernel when n*bias*ceil(count/64) <= count
+    uint32_t deep_bias = 1;        // tile kernel hands survivors to the deep kernel when n*bias*ceil(count/64) <= count
+                                   // (measured on C2/C4: split 8 + bias 0..1 is the optimum, profiles/r01_sweeps.txt)
     HtDevStage *d_stages = nullptr;
     uint32_t split_stage = 4;  // stages [0, split) in the tile kernel, [split, nstages) in the deep kernel
 
@@ -187,6 +189,7 @@ struct ht_ctx {
     HtQueueEntry *d_queue = nullptr;
     HtCounters *d_counters = nullptr;
     HtCounters h_counters;
+    uint8_t *h_pinned = nullptr;  // pinned staging: [HtCounters][HT_PINNED_HITS x ht_hit], one D2H + one sync per batch
     unsigned long long *d_stats = nullptr;      // [HT_STAT_SHARDS][64], only touched with HT_SCAN_STATS
     unsigned long long h_stage_in[64] = {0};   // windows that entered stage j ([nstages] = full survivors), last collected batch
     bool stats_enqueued = false;

@@ -16,6 +16,20 @@
 
 namespace {
 
+// XCD-aware work order shared by every detect kernel (the scan uses the same formula): the dispatcher places
+// workgroup b on XCD b % 8, so linear work item t = (b % 8) * (grid / 8) + b / 8 gives XCD k the contiguous range of
+// frames [k*n/8, (k+1)*n/8).  A frame's gray plane, pyramid and scan then stay in one XCD's L2 across the launches
+// (measured before: 8 x over-fetch of level 0 by k_resample, every XCD pulling every frame).  Speed only — nothing
+// depends on the placement.  gridDim.x must be a multiple of 8; returns false for the padding blocks.
+__device__ __forceinline__ bool xcd_item(uint32_t per_frame, uint32_t nframes, uint32_t *frame, uint32_t *item) {
+    const uint32_t chunk = gridDim.x >> 3;
+    const uint32_t t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if (t >= per_frame * nframes) return false;
+    *frame = t / per_frame;
+    *item = t - *frame * per_frame;
+    return true;
+}
+
 __device__ __forceinline__ uint32_t gray_of(uint32_t px) {  // ccv.js:29
     const double r = (double)(px & 0xffu), g = (double)((px >> 8) & 0xffu), b = (double)((px >> 16) & 0xffu);
     const double v = __dadd_rn(__dadd_rn(__dmul_rn(r, 0.3), __dmul_rn(g, 0.59)), __dmul_rn(b, 0.11));
@@ -28,11 +42,12 @@ __device__ __forceinline__ uint32_t gray_of(uint32_t px) {  // ccv.js:29
 template <bool GRAY_IN_R>
 __global__ __launch_bounds__(256) void k_gray_linear(const uint8_t *__restrict__ frames, size_t frame_stride,
                                                      uint8_t *__restrict__ arena, uint64_t arena_stride, uint32_t off0,
-                                                     uint32_t ngroups) {
-    const uint32_t f = blockIdx.y;
+                                                     uint32_t ngroups, uint32_t blocks_per_frame, uint32_t nframes) {
+    uint32_t f, blk;
+    if (!xcd_item(blocks_per_frame, nframes, &f, &blk)) return;
     const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)f * frame_stride);
     uint32_t *dst = reinterpret_cast<uint32_t *>(arena + (uint64_t)f * arena_stride + off0);
-    for (uint32_t g = blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += gridDim.x * blockDim.x) {
+    for (uint32_t g = blk * blockDim.x + threadIdx.x; g < ngroups; g += blocks_per_frame * blockDim.x) {
         const uint4 p = src[g];
         uint32_t o;
         if (GRAY_IN_R)
@@ -126,16 +141,19 @@ __device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap *s_co
 
 template <int RPT>
 __global__ __launch_bounds__(256) void k_resample(const HtResampleJob *__restrict__ jobs, const HtBlockRef *__restrict__ refs,
-                                                  uint8_t *__restrict__ arena, uint64_t arena_stride) {
+                                                  uint8_t *__restrict__ arena, uint64_t arena_stride, uint32_t blocks_per_frame,
+                                                  uint32_t nframes) {
     constexpr int TH = 16 * RPT;               // destination rows per tile
     constexpr int SR = 2 * TH + TH / 16 + 6;   // LDS source rows (ratio <= 2.04 plus the tap pair)
     __shared__ __attribute__((aligned(16))) uint8_t s_src[SR * RS_SP];
     __shared__ RsTap s_col[RS_TW], s_row[TH];
-    const HtBlockRef ref = refs[blockIdx.x];  // block -> (job, tile x, tile y): one scalar load
+    uint32_t fidx, blk;
+    if (!xcd_item(blocks_per_frame, nframes, &fidx, &blk)) return;
+    const HtBlockRef ref = refs[blk];  // block -> (job, tile x, tile y): one scalar load
     const HtResampleJob &J = jobs[ref.item];
     const int tid = (int)threadIdx.x;
     const int X0 = (int)ref.bx * RS_TW, Y0 = (int)ref.by * TH;
-    uint8_t *frame = arena + (uint64_t)blockIdx.y * arena_stride;
+    uint8_t *frame = arena + (uint64_t)fidx * arena_stride;
     const uint8_t *src = frame + J.src_off;
     const int ncols = min(RS_TW, J.dw - X0), nrows = min(TH, J.dh - Y0);  // drawn part of this tile (may be <= 0)
     const int x0 = X0 + (tid & 15) * 4, yt = Y0 + (tid >> 4);              // this thread: rows yt, yt+16, ...
@@ -229,13 +247,14 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         HtProfScope ps(c, "gray");
         if ((c->W & 3) == 0) {
             const uint32_t ngroups = (uint32_t)((size_t)c->W * c->H / 4);
-            dim3 grid(std::min<uint32_t>((ngroups + 255) / 256, 2048), c->nframes);
+            const uint32_t bpf = std::min<uint32_t>((ngroups + 255) / 256, 2048);
+            dim3 grid((bpf * (uint32_t)c->nframes + 7u) & ~7u);
             if (gray_in_r)
                 hipLaunchKernelGGL(k_gray_linear<true>, grid, dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena,
-                                   c->arena_stride, L0.off[0], ngroups);
+                                   c->arena_stride, L0.off[0], ngroups, bpf, (uint32_t)c->nframes);
             else
                 hipLaunchKernelGGL(k_gray_linear<false>, grid, dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena,
-                                   c->arena_stride, L0.off[0], ngroups);
+                                   c->arena_stride, L0.off[0], ngroups, bpf, (uint32_t)c->nframes);
         } else {
             dim3 grid((L0.stride / 4 + 63) / 64, (c->H + 3) / 4, c->nframes);
             if (gray_in_r)
@@ -250,15 +269,16 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
     for (size_t g = 1; g < c->h_gens.size(); g++) {
         if (c->gen_blocks[g] == 0) continue;
         HtProfScope ps(c, "resample");
+        const dim3 rgrid((c->gen_blocks[g] * (uint32_t)c->nframes + 7u) & ~7u);
         if (c->rs_rpt == 4)
-            hipLaunchKernelGGL(k_resample<4>, dim3(c->gen_blocks[g], c->nframes), dim3(256), 0, c->stream, c->d_gens[g],
-                               c->d_gen_blocks[g], c->d_arena, c->arena_stride);
+            hipLaunchKernelGGL(k_resample<4>, rgrid, dim3(256), 0, c->stream, c->d_gens[g], c->d_gen_blocks[g], c->d_arena,
+                               c->arena_stride, c->gen_blocks[g], (uint32_t)c->nframes);
         else if (c->rs_rpt == 2)
-            hipLaunchKernelGGL(k_resample<2>, dim3(c->gen_blocks[g], c->nframes), dim3(256), 0, c->stream, c->d_gens[g],
-                               c->d_gen_blocks[g], c->d_arena, c->arena_stride);
+            hipLaunchKernelGGL(k_resample<2>, rgrid, dim3(256), 0, c->stream, c->d_gens[g], c->d_gen_blocks[g], c->d_arena,
+                               c->arena_stride, c->gen_blocks[g], (uint32_t)c->nframes);
         else
-            hipLaunchKernelGGL(k_resample<1>, dim3(c->gen_blocks[g], c->nframes), dim3(256), 0, c->stream, c->d_gens[g],
-                               c->d_gen_blocks[g], c->d_arena, c->arena_stride);
+            hipLaunchKernelGGL(k_resample<1>, rgrid, dim3(256), 0, c->stream, c->d_gens[g], c->d_gen_blocks[g], c->d_arena,
+                               c->arena_stride, c->gen_blocks[g], (uint32_t)c->nframes);
         HT_HIP(c, hipGetLastError());
     }
     return HT_OK;

@@ -394,7 +394,8 @@ __device__ __forceinline__ double patch_stage_sum_exact(const uint8_t *patch, co
     return sum;
 }
 
-__global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+// v1: straightforward per-stage loop (46 VGPRs, 8 waves/SIMD); kept for A/B against the prefetching version below
+__global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep_v1(const uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                                const HtDevLevel *__restrict__ levels, int next,
                                                                const HtPatchFeature *__restrict__ feats,
                                                                const HtDevStage *__restrict__ stages, int nstages, int use_int,
@@ -451,6 +452,156 @@ __global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__
                 }
                 conf = sum;
             }
+        }
+        if (alive && lane == 0) {
+            if (my_stats) atomicAdd(&my_stats[nstages], 1ull);
+            const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
+            if (pos < hit_cap) {
+                ht_hit h;
+                h.frame = ent.frame;
+                h.x = ent.x;
+                h.y = ent.y;
+                h.scale = ent.scale;
+                h.q = ent.q;
+                h.reserved0 = 0;
+                h.reserved1 = 0;
+                h.sum = conf;
+                hits[pos] = h;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the next window overwrites the patch
+    }
+}
+
+// registers holding one lane's feature record (loaded one chunk ahead of its use)
+struct PatchFeatRegs {
+    uint4 P, N;        // 8 + 8 u16 offsets
+    long long a0i, a1i;
+};
+__device__ __forceinline__ PatchFeatRegs load_feat(const HtPatchFeature *__restrict__ fp) {
+    PatchFeatRegs r;
+    r.P = *reinterpret_cast<const uint4 *>(fp->poff);
+    r.N = *reinterpret_cast<const uint4 *>(fp->noff);
+    const longlong2 A = *reinterpret_cast<const longlong2 *>(&fp->a0i);
+    r.a0i = A.x;
+    r.a1i = A.y;
+    return r;
+}
+__device__ __forceinline__ bool fire_regs(const uint8_t *patch, const PatchFeatRegs &f, uint32_t maxpts) {
+    const uint32_t pw[4] = {f.P.x, f.P.y, f.P.z, f.P.w}, nw[4] = {f.N.x, f.N.y, f.N.z, f.N.w};
+    uint32_t pmin = 255u, nmax = 0u;
+#pragma unroll
+    for (uint32_t j = 0; j < HT_MAXPTS; j++) {
+        if (j < maxpts) {
+            const uint32_t po = (j & 1) ? (pw[j >> 1] >> 16) : (pw[j >> 1] & 0xffffu);
+            const uint32_t no = (j & 1) ? (nw[j >> 1] >> 16) : (nw[j >> 1] & 0xffffu);
+            pmin = min(pmin, (uint32_t)patch[po]);
+            nmax = max(nmax, (uint32_t)patch[no]);
+        }
+    }
+    return pmin > nmax;
+}
+
+__global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+                                                               const HtDevLevel *__restrict__ levels, int next,
+                                                               const HtPatchFeature *__restrict__ feats,
+                                                               const HtDevStage *__restrict__ stages, int nstages, int use_int,
+                                                               const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
+                                                               ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr,
+                                                               unsigned long long *__restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DEEP_WAVES][PATCH_BYTES];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint8_t *patch = s_patch[wv];
+    const uint32_t wave = blockIdx.x * DEEP_WAVES + wv, nwaves = gridDim.x * DEEP_WAVES;
+    unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
+    const uint32_t n = min(ctr->nqueue, queue_cap);
+    for (uint32_t e = wave; e < n; e += nwaves) {
+        const HtQueueEntry ent = queue[e];
+        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
+                     (uint32_t)ent.y)
+        int j = (int)ent.pad;  // first stage to run here
+        HtDevStage st = stages[j];
+        // first feature chunk and the window patch are fetched together (one memory latency)
+        PatchFeatRegs cur;
+        if (lane < st.count) cur = load_feat(feats + st.first + lane);
+        {
+            uint32_t pa[5], pb[3], pc = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {  // plane 0: 24 rows x 12 halfwords (window origin is 2-byte aligned)
+                const uint32_t i = lane + 64u * k, r = i / 12u, c2 = (i - r * 12u) * 2u;
+                pa[k] = 0;
+                if (i < 288u) pa[k] = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {  // plane 1: 12 x 12 bytes
+                const uint32_t i = lane + 64u * k, r = i / 12u, c = i - r * 12u;
+                pb[k] = 0;
+                if (i < 144u) pb[k] = fb[o1 + r * (uint32_t)s1 + c];
+            }
+            if (lane < 36u) {  // plane 2: 6 x 6 bytes
+                const uint32_t r = lane / 6u, c = lane - r * 6u;
+                pc = fb[o2 + r * (uint32_t)s2 + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t i = lane + 64u * k;
+                if (i < 288u) *reinterpret_cast<uint16_t *>(&patch[2u * i]) = (uint16_t)pa[k];  // 24-byte rows are contiguous
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t i = lane + 64u * k;
+                if (i < 144u) patch[PATCH1 + i] = (uint8_t)pb[k];
+            }
+            if (lane < 36u) patch[PATCH2 + lane] = (uint8_t)pc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool alive = true;
+        double conf = 0.0;
+        uint32_t kb = 0;       // chunk base inside stage j
+        long long acc = 0;
+        while (true) {
+            // prefetch the next chunk (same stage, or speculatively the first chunk of the next stage)
+            const bool stage_ends = kb + 64u >= st.count;
+            int jn = j;
+            uint32_t kbn = kb + 64u;
+            HtDevStage stn = st;
+            if (stage_ends) {
+                jn = j + 1;
+                kbn = 0;
+                if (jn < nstages) stn = stages[jn];
+            }
+            PatchFeatRegs nxt = cur;
+            if (jn < nstages && kbn + lane < stn.count) nxt = load_feat(feats + stn.first + kbn + lane);
+            if (kb == 0 && lane == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
+            if (use_int) {
+                if (kb + lane < st.count) acc += fire_regs(patch, cur, st.maxpts) ? cur.a1i : cur.a0i;
+            }
+            if (stage_ends) {
+                bool need_exact = true;
+                if (use_int) {
+                    const long long Ssum = wave_sum_i64(acc);
+                    acc = 0;
+                    if (Ssum < st.thri) {  // sum < threshold decided exactly, independent of summation order
+                        alive = false;
+                        break;
+                    }
+                    need_exact = (Ssum == st.thri) || (j == nstages - 1);
+                }
+                if (need_exact) {
+                    const double sum = patch_stage_sum_exact(patch, feats + st.first, st.count, st.maxpts, lane);
+                    if (sum < st.threshold) {  // ccv.js:222
+                        alive = false;
+                        break;
+                    }
+                    conf = sum;
+                }
+                if (jn >= nstages) break;
+            }
+            j = jn;
+            kb = kbn;
+            st = stn;
+            cur = nxt;
         }
         if (alive && lane == 0) {
             if (my_stats) atomicAdd(&my_stats[nstages], 1ull);
@@ -658,7 +809,8 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
         HT_HIP(c, hipGetLastError());
         return HT_OK;
     }
-    const int split = (flags & HT_SCAN_NO_SPLIT) ? (int)c->nstages : (int)c->split_stage;
+    if (const char *e = getenv("HT_DEBUG_SPLIT")) c->split_stage = (uint32_t)std::max(1, atoi(e));  // measurement knob
+    const int split = (flags & HT_SCAN_NO_SPLIT) ? (int)c->nstages : (int)std::min<uint32_t>(c->split_stage, c->nstages);
     const uint64_t total64 = (uint64_t)c->tiles_per_frame * (uint64_t)c->nframes;
     if (total64 > 0x7fffff00ull) return ht_fail(c, HT_ERR_INVALID, "ht_detect: batch too large for one launch");
     const uint32_t total = (uint32_t)total64;
@@ -681,6 +833,12 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     }
     if (split < (int)c->nstages) {
         HtProfScope ps(c, "scan_deep");
+        const char *dv = getenv("HT_DEBUG_DEEP_V");
+        if (dv && atoi(dv) == 1)
+            hipLaunchKernelGGL(k_scan_deep_v1, dim3(2048), dim3(64 * DEEP_WAVES), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
+                               c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
+                               c->hit_capacity, c->d_counters, stats);
+        else
         hipLaunchKernelGGL(k_scan_deep, dim3(2048), dim3(64 * DEEP_WAVES), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                            c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
                            c->hit_capacity, c->d_counters, stats);

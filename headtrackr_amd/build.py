@@ -24,6 +24,8 @@ HIP_FLAGS = [
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC,
 ]
+if os.environ.get("HT_TILE_NT"):  # measurement knob: threads per scan-tile workgroup (256 default, 512)
+    HIP_FLAGS.append("-DHT_TILE_NT=" + os.environ["HT_TILE_NT"])
 
 
 def _newer(target: str, deps) -> bool:

@@ -34,7 +34,10 @@ namespace {
 // tile geometry (window = 24x24, see ht_scan_tile_tables for the check)
 constexpr int TXH = 64;                 // tile width  in half-window steps X'
 constexpr int TYH = 32;                 // tile height in half-window steps Y'
-constexpr int NT = 256;                 // threads per workgroup
+#ifndef HT_TILE_NT
+#define HT_TILE_NT 256
+#endif
+constexpr int NT = HT_TILE_NT;          // threads per workgroup (256: 4 waves/SIMD at <=128 VGPRs; 512: 8 waves/SIMD at <=64)
 constexpr int PITCH0 = 2 * TXH + 24;    // 152: plane-0 bytes per LDS row
 constexpr int ROWS0 = 2 * TYH + 22;     // 86
 constexpr int P0_BYTES = PITCH0 * ROWS0;  // 13072
@@ -114,7 +117,7 @@ __device__ __forceinline__ double eval_stage_lds(const uint8_t *lds, uint32_t B,
 }
 
 template <bool GEN>
-__global__ __launch_bounds__(NT, 4) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+__global__ __launch_bounds__(NT, NT / 64) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                    const HtDevLevel *__restrict__ levels, const HtScanScale *__restrict__ scales,
                                                    const HtBlockRef *__restrict__ tile_refs, const HtTileFeature *__restrict__ feats,
                                                    const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,

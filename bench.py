@@ -115,15 +115,9 @@ def main():
         hits, counts = ctx.detect_collect(cap=1 << 16)
         if a.workload == "c3":
             # detect once, then 60 camshift track() calls on the (static) batch, SURVEY.md §8 C3
-            starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
-            rects = []
-            for f in range(nf):
-                if counts[f]:
-                    r = ctx.group_rects(ctx.hits_to_rects(hits[starts[f] : starts[f + 1]]), 1)
-                    b = r[np.argmax(r["confidence"])]
-                    rects.append((int(np.floor(b["x"])), int(np.floor(b["y"])), int(np.floor(b["width"])), int(np.floor(b["height"]))))
-                else:
-                    rects.append((W // 4, H // 4, W // 2, H // 2))
+            best = ctx.best_faces(hits, counts, 1)  # facetrackr.js:147-175 for the whole batch
+            fl = np.floor(np.stack([best["x"], best["y"], best["width"], best["height"]], axis=1)).astype(np.int64)  # facetrackr.js:101-106
+            rects = [tuple(fl[f]) if best["neighbors"][f] > 0 else (W // 4, H // 4, W // 2, H // 2) for f in range(nf)]
             ctx.camshift_init(rects)
             for it in range(60):
                 ctx.camshift_track(nf, calc_angles=True, fetch=(it == 59))

@@ -132,6 +132,15 @@ class Context:
         self._check(self._lib.ht_group_rects(rects.ctypes.data, len(rects), min_neighbors, out.ctypes.data, C.byref(n)))
         return out[: n.value].copy()
 
+    def best_faces(self, hits: np.ndarray, counts: np.ndarray, min_neighbors: int = 1) -> np.ndarray:
+        """facetrackr's choice per frame (facetrackr.js:147-175): the grouped rect with the highest confidence."""
+        hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+        counts = np.ascontiguousarray(counts, dtype=np.uint32)
+        out = np.zeros(len(counts), dtype=RECT_DTYPE)
+        self._check(self._lib.ht_best_faces(self._h, hits.ctypes.data if len(hits) else None, counts.ctypes.data, len(counts), min_neighbors,
+                                            out.ctypes.data))
+        return out
+
     def detect_objects(self, frames: np.ndarray, min_neighbors: int = 1, flags: int = HT_INPUT_RGBA):
         """Per frame: the list ccv.detect_objects(canvas, cascade, interval, min_neighbors) returns (ccv.js:109-333)."""
         hits, counts = self.detect_raw(frames, flags)

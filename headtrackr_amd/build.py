@@ -24,8 +24,9 @@ HIP_FLAGS = [
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC,
 ]
-if os.environ.get("HT_TILE_NT"):  # measurement knob: threads per scan-tile workgroup (256 default, 512)
-    HIP_FLAGS.append("-DHT_TILE_NT=" + os.environ["HT_TILE_NT"])
+for _knob in ("HT_TILE_NT", "HT_TILE_TYH", "HT_TILE_WPS"):  # measurement knobs: scan-tile workgroup size / tile height / waves per SIMD
+    if os.environ.get(_knob):
+        HIP_FLAGS.append(f"-D{_knob}=" + os.environ[_knob])
 
 
 def _newer(target: str, deps) -> bool:

@@ -756,6 +756,35 @@ extern "C" ht_status ht_group_rects(const ht_rect *seq, uint32_t n, int32_t min_
     return HT_OK;
 }
 
+extern "C" ht_status ht_best_faces(const ht_ctx *c, const ht_hit *hits, const uint32_t *counts, int32_t nframes, int32_t min_neighbors,
+                                   ht_rect *best) {
+    if (!c || !counts || !best || nframes < 0) return HT_ERR_INVALID;
+    std::vector<ht_rect> seq, grouped;
+    size_t k = 0;
+    for (int f = 0; f < nframes; f++) {
+        const uint32_t n = counts[f];
+        ht_rect r = {0, 0, 0, 0, -10000.0, 0, 0};  // facetrackr.TrackObj defaults, facetrackr.js:233-241
+        if (n) {
+            if (!hits) return HT_ERR_INVALID;
+            seq.resize(n);
+            grouped.resize(n);
+            ht_status st = ht_hits_to_rects(c, hits + k, n, seq.data());
+            if (st != HT_OK) return st;
+            uint32_t ng = n;
+            if (min_neighbors > 0) {
+                if ((st = ht_group_rects(seq.data(), n, min_neighbors, grouped.data(), &ng)) != HT_OK) return st;
+            } else {
+                grouped = seq;
+            }
+            for (uint32_t i = 0; i < ng; i++)  // facetrackr.js:157-165
+                if (i == 0 || grouped[i].confidence > r.confidence) r = grouped[i];
+        }
+        best[f] = r;
+        k += n;
+    }
+    return HT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // measurement
 

@@ -33,7 +33,13 @@ namespace {
 
 // tile geometry (window = 24x24, see ht_scan_tile_tables for the check)
 constexpr int TXH = 64;                 // tile width  in half-window steps X'
-constexpr int TYH = 32;                 // tile height in half-window steps Y'
+#ifndef HT_TILE_TYH
+#define HT_TILE_TYH 32
+#endif
+#ifndef HT_TILE_WPS
+#define HT_TILE_WPS (HT_TILE_NT / 64)
+#endif
+constexpr int TYH = HT_TILE_TYH;        // tile height in half-window steps Y'
 #ifndef HT_TILE_NT
 #define HT_TILE_NT 256
 #endif
@@ -117,7 +123,7 @@ __device__ __forceinline__ double eval_stage_lds(const uint8_t *lds, uint32_t B,
 }
 
 template <bool GEN>
-__global__ __launch_bounds__(NT, NT / 64) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+__global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                    const HtDevLevel *__restrict__ levels, const HtScanScale *__restrict__ scales,
                                                    const HtBlockRef *__restrict__ tile_refs, const HtTileFeature *__restrict__ feats,
                                                    const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,

@@ -60,7 +60,7 @@ SYMBOLS = [
     "ht_create", "ht_destroy", "ht_last_error", "ht_abi_version", "ht_set_geometry", "ht_num_levels", "ht_plane",
     "ht_windows_per_frame", "ht_pyramid_bytes_per_frame", "ht_upload_frames", "ht_bind_frames_device", "ht_detect_enqueue",
     "ht_detect_collect", "ht_detect_batch", "ht_pyramid_readback", "ht_stage_counts", "ht_grayscale_batch",
-    "ht_whitebalance_batch", "ht_hits_to_rects", "ht_group_rects", "ht_camshift_reserve", "ht_camshift_init_batch",
+    "ht_whitebalance_batch", "ht_hits_to_rects", "ht_group_rects", "ht_best_faces", "ht_camshift_reserve", "ht_camshift_init_batch",
     "ht_camshift_track_batch", "ht_allgather_records", "ht_profile", "ht_kernel_times", "ht_stream", "ht_synchronize",
 ]
 
@@ -115,6 +115,8 @@ def lib():
     L.ht_hits_to_rects.argtypes = [vp, vp, u32, vp]
     L.ht_group_rects.restype = i32
     L.ht_group_rects.argtypes = [vp, u32, i32, vp, C.POINTER(u32)]
+    L.ht_best_faces.restype = i32
+    L.ht_best_faces.argtypes = [vp, vp, vp, i32, i32, vp]
     L.ht_camshift_reserve.restype = i32
     L.ht_camshift_reserve.argtypes = [vp, i32]
     L.ht_camshift_init_batch.restype = i32

@@ -159,6 +159,13 @@ ht_status ht_hits_to_rects(const ht_ctx *ctx, const ht_hit *hits, uint32_t n, ht
 /* ccv.array_group + averaging + nested-rect filter (ccv.js:34-107, 249-332). *nout <= n. */
 ht_status ht_group_rects(const ht_rect *seq, uint32_t n, int32_t min_neighbors, ht_rect *out, uint32_t *nout);
 
+/* facetrackr.Tracker.doVJDetection's selection for a whole batch (facetrackr.js:147-175): per frame, group the raw hits
+ * with min_neighbors and keep the rect with the highest confidence (strict '>', first wins).  best[f].neighbors == 0 and
+ * confidence == -10000 when frame f has no detection (facetrackr.js:239). counts[f] = raw hits of frame f, hits sorted as
+ * ht_detect_collect returns them. */
+ht_status ht_best_faces(const ht_ctx *ctx, const ht_hit *hits, const uint32_t *counts, int32_t nframes, int32_t min_neighbors,
+                        ht_rect *best);
+
 /* ---- camshift: camshift.Tracker (camshift.js:148-354), one tracker per stream ----------------------------- */
 
 /* (Re)allocates per-stream tracker state for n streams. */

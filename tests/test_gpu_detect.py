@@ -176,3 +176,16 @@ def test_queue_overflow_falls_back_inline(cascade):
     ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(6)])
     assert_hits_equal(hits, ref)
     c.close()
+
+
+def test_best_faces_matches_per_frame_grouping(ctx):
+    frames = synth.mixed_batch(9, 320, 240, seed0=1234)
+    hits, counts = ctx.detect_raw(frames)
+    best = ctx.best_faces(hits, counts, 1)
+    per = ctx.detect_objects(frames, min_neighbors=1)
+    for f in range(9):
+        if len(per[f]) == 0:
+            assert best[f]["neighbors"] == 0 and best[f]["confidence"] == -10000.0
+        else:
+            b = per[f][int(np.argmax(per[f]["confidence"]))]
+            assert best[f].tobytes() == b.tobytes()

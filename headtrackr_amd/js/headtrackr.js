@@ -465,16 +465,20 @@ headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
         Math.floor(result.width), Math.floor(result.height)));
     }
     current = result;
-    if (result.detection === 'CS' && params.sendEvents && typeof document !== 'undefined') { /* facetrackr.js:112-125 */
-      const evt = document.createEvent('Event');
-      evt.initEvent('facetrackingEvent', true, true);
+    if (result.detection === 'CS' && params.sendEvents) { /* facetrackr.js:112-125 */
+      const hasDoc = typeof document !== 'undefined' && document.createEvent;
+      const evt = hasDoc ? document.createEvent('Event') : { type: 'facetrackingEvent' };
+      if (hasDoc) evt.initEvent('facetrackingEvent', true, true);
       evt.height = result.height; evt.width = result.width; evt.angle = result.angle; evt.x = result.x; evt.y = result.y;
       evt.confidence = result.confidence; evt.detection = result.detection; evt.time = result.time;
-      document.dispatchEvent(evt);
+      if (hasDoc) document.dispatchEvent(evt);
+      if (params.onEvent) params.onEvent('facetrackingEvent', evt); /* Node hosts without a DOM */
     }
   };
 
   this.getTrackingObject = function () { return current.clone(); };
 };
+
+require('./tracker.js')(headtrackr); /* Smoother, headposition, Tracker facade (host post-processing) */
 
 module.exports = headtrackr;

@@ -127,6 +127,106 @@ function runFacetrackr(cs, base) {
   return out;
 }
 
+/* headtrackr.Smoother (smoother.js:13-88): feed positions, record what smooth() returns */
+function runSmoother(cs) {
+  const out = { name: cs.name, kind: 'smoother', alpha: cs.alpha, interval: cs.interval, positions: cs.positions, calls: [] };
+  const sm = new headtrackr.Smoother(cs.alpha, cs.interval);
+  cs.positions.forEach(function (p, i) {
+    const pos = { x: p[0], y: p[1], z: p[2], width: p[3], height: p[4] };
+    if (!sm.initialized && i >= (cs.init_at || 0)) sm.init(pos);
+    const r = sm.smooth(pos);
+    out.calls.push(r === false ? null : [r.x, r.y, r.z, r.width, r.height]);
+  });
+  return out;
+}
+
+/* headtrackr.headposition.Tracker (headposition.js:35-201) */
+function runHeadposition(cs) {
+  const out = { name: cs.name, kind: 'headposition', camw: cs.camw, camh: cs.camh, params: cs.params || {}, faces: cs.faces, calls: [], events: [] };
+  const listener = function (e) { out.events.push([e.x, e.y, e.z]); };
+  document.addEventListener('headtrackingEvent', listener);
+  const f0 = cs.faces[0];
+  const hp = new headtrackr.headposition.Tracker({ x: f0[0], y: f0[1], width: f0[2], height: f0[3] }, cs.camw, cs.camh, Object.assign({}, cs.params || {}));
+  out.fov = hp.getFOV();
+  cs.faces.forEach(function (f) {
+    const r = hp.track({ x: f[0], y: f[1], width: f[2], height: f[3] });
+    out.calls.push([r.x, r.y, r.z]);
+  });
+  document.removeEventListener('headtrackingEvent', listener);
+  return out;
+}
+
+/* The per-frame body of headtrackr.Tracker's loop (main.js:168-305) composed from the reference's own objects, without
+ * the webcam / DOM plumbing: facetrackr -> lost-track handling -> Smoother -> headposition.  Records status messages,
+ * the (smoothed) face object and the head position per frame. */
+function runPipeline(cs, base) {
+  const params = Object.assign({ smoothing: true, retryDetection: true, detectionInterval: 20, cameraOffset: 11.5, calcAngles: false, headPosition: true }, cs.params || {});
+  const out = { name: cs.name, kind: 'pipeline', w: cs.w, h: cs.h, params: cs.params || {}, calls: [] };
+  const canvas = new shim.Canvas(cs.w, cs.h);
+  let facetracker, headposition, faceFound = false, firstRun = true, fov = 0;
+  const headDiagonal = [];
+  const smoother = new headtrackr.Smoother(0.35, params.detectionInterval + 15);
+  const headEvents = [];
+  const hl = function (e) { headEvents.push([e.x, e.y, e.z]); };
+  document.addEventListener('headtrackingEvent', hl);
+  for (let i = 0; i < cs.frames.length; i++) {
+    const status = [];
+    canvas.loadRGBA(fs.readFileSync(path.resolve(base, cs.frames[i])));
+    if (facetracker === undefined) {
+      facetracker = new headtrackr.facetrackr.Tracker({ debug: false, calcAngles: params.calcAngles, whitebalancing: cs.whitebalancing !== false });
+      facetracker.init(canvas);
+    }
+    facetracker.track();
+    let faceObj = facetracker.getTrackingObject();
+    if (faceObj.detection === 'WB') status.push('whitebalance');
+    if (firstRun && faceObj.detection === 'VJ') status.push('detecting');
+    let head = null;
+    const nh = headEvents.length;
+    if (!(faceObj.confidence === 0) && faceObj.detection === 'CS') {
+      if (faceObj.width === 0 || faceObj.height === 0) {
+        status.push('redetecting');
+        facetracker = new headtrackr.facetrackr.Tracker({ whitebalancing: false, debug: false, calcAngles: params.calcAngles });
+        facetracker.init(canvas);
+        faceFound = false;
+        headposition = undefined;
+      } else {
+        if (!faceFound) { status.push('found'); faceFound = true; }
+        if (params.smoothing) {
+          if (!smoother.initialized) smoother.init(faceObj);
+          faceObj = smoother.smooth(faceObj);
+        }
+        if (headposition === undefined && params.headPosition) {
+          let stable = false;
+          const headdiag = Math.sqrt(faceObj.width * faceObj.width + faceObj.height * faceObj.height);
+          if (headDiagonal.length < 6) headDiagonal.push(headdiag);
+          else {
+            headDiagonal.splice(0, 1); headDiagonal.push(headdiag);
+            if ((Math.max.apply(null, headDiagonal) - Math.min.apply(null, headDiagonal)) < 5) stable = true;
+          }
+          if (stable) {
+            if (firstRun) {
+              headposition = new headtrackr.headposition.Tracker(faceObj, cs.w, cs.h, { distance_from_camera_to_screen: params.cameraOffset });
+              fov = headposition.getFOV();
+              firstRun = false;
+            } else {
+              headposition = new headtrackr.headposition.Tracker(faceObj, cs.w, cs.h, { fov: fov, distance_from_camera_to_screen: params.cameraOffset });
+            }
+            headposition.track(faceObj);
+          }
+        } else if (params.headPosition) {
+          headposition.track(faceObj);
+        }
+      }
+    }
+    if (headEvents.length > nh) head = headEvents[headEvents.length - 1];
+    out.calls.push({ frame: i, status: status, detection: faceObj.detection, x: faceObj.x, y: faceObj.y, width: faceObj.width, height: faceObj.height,
+      angle: faceObj.angle, confidence: faceObj.confidence, head: head });
+  }
+  document.removeEventListener('headtrackingEvent', hl);
+  out.fov = fov;
+  return out;
+}
+
 function main() {
   const jobFile = process.argv[2], outFile = process.argv[3];
   const job = JSON.parse(fs.readFileSync(jobFile, 'utf8'));
@@ -139,6 +239,9 @@ function main() {
     if (cs.kind === 'detect') r = runDetect(cs, base);
     else if (cs.kind === 'camshift') r = runCamshift(cs, base);
     else if (cs.kind === 'facetrackr') r = runFacetrackr(cs, base);
+    else if (cs.kind === 'smoother') r = runSmoother(cs);
+    else if (cs.kind === 'headposition') r = runHeadposition(cs);
+    else if (cs.kind === 'pipeline') r = runPipeline(cs, base);
     else throw new Error('unknown case kind ' + cs.kind);
     r.gen = cs.gen;                         /* how make_golden.py synthesised the input (echoed for the tests) */
     res.cases.push(r);

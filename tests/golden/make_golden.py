@@ -90,6 +90,25 @@ def facetrackr_cases():
     return cs
 
 
+def post_cases():
+    """Smoother, headposition and the per-frame body of headtrackr.Tracker (host post-processing)."""
+    cs = []
+    r = synth.lcg_stream(777, 400).astype("int64") >> 16
+    pos = [[100 + int(r[5 * i] % 40), 80 + int(r[5 * i + 1] % 30), 50 + int(r[5 * i + 2] % 9), 90 + int(r[5 * i + 3] % 12), 100 + int(r[5 * i + 4] % 12)] for i in range(25)]
+    cs.append(dict(name="smoother_default", kind="smoother", alpha=0.35, interval=35, positions=pos))
+    cs.append(dict(name="smoother_late_init", kind="smoother", alpha=0.5, interval=20, positions=pos[:8], init_at=3))
+    faces = [[160 + int(r[100 + 4 * i] % 200) - 100, 120 + int(r[101 + 4 * i] % 160) - 80, 80 + int(r[102 + 4 * i] % 30), 96 + int(r[103 + 4 * i] % 30)] for i in range(30)]
+    faces += [[30, 120, 80, 100], [300, 30, 70, 90], [20, 20, 60, 70], [160, 230, 90, 110], [310, 235, 50, 60]]  # edge / corner corrections
+    cs.append(dict(name="headposition_default", kind="headposition", camw=320, camh=240, params={}, faces=faces))
+    cs.append(dict(name="headposition_fov_noedge", kind="headposition", camw=320, camh=240, faces=faces,
+                   params=dict(fov=45, edgecorrection=False, distance_from_camera_to_screen=8)))
+    W, H = 320, 240
+    gens = [dict(family="face", faces=[[100 + k, 60 + (k % 3), 96]]) for k in range(14)] + \
+           [dict(family="face", faces=[], gray=250)] * 2 + [dict(family="face", faces=[[60, 50, 110]])] * 10
+    cs.append(dict(name="pipeline_nowb", kind="pipeline", w=W, h=H, whitebalancing=False, params=dict(calcAngles=True), gens=gens))
+    return cs
+
+
 def run(cases, out_name):
     with tempfile.TemporaryDirectory() as td:
         cache = {}
@@ -110,6 +129,8 @@ def run(cases, out_name):
             if "gens" in c:
                 c["frames"] = [frame_file(g, c["w"], c["h"]) for g in c["gens"]]
                 c["gen"] = c["gens"]
+            if c["kind"] in ("smoother", "headposition"):
+                c["gen"] = None
             job["cases"].append(c)
         jf = os.path.join(td, "job.json")
         with open(jf, "w") as f:
@@ -128,3 +149,4 @@ if __name__ == "__main__":
     run(detect_cases(), "detect.json")
     run(camshift_cases(), "camshift.json")
     run(facetrackr_cases(), "facetrackr.json")
+    run(post_cases(), "post.json")

@@ -30,6 +30,32 @@ golden.cases.forEach(function (cs) {
     });
   }
 });
+/* host post-processing (SURVEY.md §8f) against the reference-JS vectors: Smoother and headposition are pure math */
+const post = JSON.parse(fs.readFileSync(path.join(root, 'tests', 'golden', 'post.json'), 'utf8'));
+post.cases.forEach(function (cs) {
+  if (cs.kind === 'smoother') {
+    const sm = new ht.Smoother(cs.alpha, cs.interval);
+    const first = cs.calls.findIndex(function (c) { return c !== null; });
+    cs.positions.forEach(function (p, i) {
+      const pos = { x: p[0], y: p[1], z: p[2], width: p[3], height: p[4] };
+      if (!sm.initialized && i >= first) sm.init(pos);
+      const r = sm.smooth(pos);
+      if (cs.calls[i] === null) check(r === false, cs.name + ': call ' + i + ' should return false');
+      else check(r !== false && [r.x, r.y, r.z, r.width, r.height].every(function (v, k) { return v === cs.calls[i][k]; }), cs.name + ': call ' + i);
+    });
+  } else if (cs.kind === 'headposition') {
+    const f0 = cs.faces[0];
+    const hp = new ht.headposition.Tracker({ x: f0[0], y: f0[1], width: f0[2], height: f0[3] }, cs.camw, cs.camh, Object.assign({}, cs.params));
+    check(hp.getFOV() === cs.fov, cs.name + ': fov ' + hp.getFOV() + ' vs ' + cs.fov);
+    cs.faces.forEach(function (f, i) {
+      const r = hp.track({ x: f[0], y: f[1], width: f[2], height: f[3] });
+      check(r.x === cs.calls[i][0] && r.y === cs.calls[i][1] && r.z === cs.calls[i][2], cs.name + ': track ' + i + ' ' + JSON.stringify([r.x, r.y, r.z]) + ' vs ' + JSON.stringify(cs.calls[i]));
+    });
+  }
+});
+['Smoother', 'Tracker'].forEach(function (k) { check(typeof ht[k] === 'function', 'missing ' + k); });
+check(typeof ht.headposition.Tracker === 'function' && typeof ht.headposition.TrackObj === 'function', 'missing headposition');
+
 /* the addon must load and expose the C-ABI wrappers even without a GPU */
 try {
   const addon = require(path.join(root, 'headtrackr_amd', 'js', 'headtrackr_hip.node'));

@@ -82,6 +82,27 @@ job.facetrackr.forEach(function (cs) {
   check(events.length === g.events.length, cs.name + ': facetrackingEvent count ' + events.length + ' vs ' + g.events.length);
 });
 
+/* headtrackr.Tracker facade: one step() per frame == the reference's track() body (facetrackr -> Smoother -> headposition) */
+(job.pipeline || []).forEach(function (cs) {
+  const g = cs.golden;
+  const statuses = [];
+  const canvas = new Canvas(cs.w, cs.h);
+  const tr = new headtrackr.Tracker(Object.assign({ whitebalancing: g.whitebalancing !== false, onEvent: function (t, e) { if (t === 'headtrackrStatus') statuses.push(e.status); } }, g.params));
+  tr.init(canvas, canvas);
+  g.calls.forEach(function (call, i) {
+    statuses.length = 0;
+    canvas.setFrame(fs.readFileSync(path.resolve(base, cs.frames[i])));
+    const r = tr.step();
+    check(JSON.stringify(statuses) === JSON.stringify(call.status), cs.name + ' frame ' + i + ': status ' + JSON.stringify(statuses) + ' vs ' + JSON.stringify(call.status));
+    check(r.face.detection === call.detection, cs.name + ' frame ' + i + ': detection');
+    const tol = call.detection === 'CS' ? 1.5 : 0; /* smoothed camshift output: +-1 px budget of the track itself */
+    check(near(r.face.x, call.x, tol) && near(r.face.y, call.y, tol) && near(r.face.width, call.width, 4) && near(r.face.height, call.height, 4), cs.name + ' frame ' + i + ': face');
+    if (call.head === null) check(r.head === null, cs.name + ' frame ' + i + ': no head position expected');
+    else check(r.head !== null && near(r.head.x, call.head[0], 0.5) && near(r.head.y, call.head[1], 0.5) && near(r.head.z, call.head[2], 2.5), cs.name + ' frame ' + i + ': head ' + JSON.stringify(r.head) + ' vs ' + JSON.stringify(call.head));
+  });
+  check(near(tr.getFOV(), g.fov, 1.0), cs.name + ': fov');
+});
+
 /* batch entry point (async): same frames in one call == per-frame results */
 (async function () {
   if (job.detect.length) {

@@ -45,7 +45,8 @@ def test_js_host_parity_on_gpu(tmp_path):
             cache[key] = fn
         return cache[key]
 
-    job = {"detect": [], "camshift": [], "facetrackr": []}
+    post = load_golden("post.json")
+    job = {"detect": [], "camshift": [], "facetrackr": [], "pipeline": []}
     for c in det["cases"]:
         if c["w"] > 640:
             continue
@@ -57,6 +58,11 @@ def test_js_host_parity_on_gpu(tmp_path):
     for c in ft["cases"]:
         job["facetrackr"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=[ffile(g, c["w"], c["h"]) for g in c["gen"]],
                                       golden={k: c[k] for k in ("params", "calls", "events")}))
+    for c in post["cases"]:
+        if c["kind"] == "pipeline":
+            g = {k: c[k] for k in ("params", "calls", "fov")}
+            g["whitebalancing"] = False
+            job["pipeline"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=[ffile(x, c["w"], c["h"]) for x in c["gen"]], golden=g))
     jf = tmp_path / "job.json"
     jf.write_text(json.dumps(job))
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "parity_gpu.js"), str(jf)], capture_output=True, text=True, timeout=600)

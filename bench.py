@@ -33,13 +33,86 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: 256 for c2/c3, 128 for c4)")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn")
     return ap.parse_args()
+
+
+def stream_bench(a, torch, dist, rank, world, local):
+    """C5 (BASELINE.json configs[4]): one live 1920x1080 feed per GPU; every frame travels host -> GPU (pinned buffer,
+    PCIe) -> result on the host.  Frame 0, 30, 60, ... : full-cascade detect + camshift.initTracker on the best face
+    (facetrackr.js:97-108); every other frame: camshift.track.  A step is one frame of every feed; reports aggregate
+    frames/s and the per-frame end-to-end latency distribution."""
+    from headtrackr_amd import synth
+    from headtrackr_amd.api import Context
+
+    W, H = 1920, 1080
+    nuniq = 30
+    host = torch.empty((nuniq, H, W, 4), dtype=torch.uint8).pin_memory()
+    hv = host.numpy()
+    for k in range(nuniq):  # a face drifting 3 px / frame over a flat background
+        hv[k] = synth.face_frame(W, H, [(700 + 3 * k + 40 * rank, 300 + k, 360)])
+    ctx = Context(device=local)
+    ctx.set_geometry(W, H, 1)
+    ctx.camshift_reserve(1)
+    fbytes = W * H * 4
+    lat = {"detect": [], "track": []}
+
+    def frame(i):
+        t0 = time.perf_counter()
+        ctx.upload_ptr(host.data_ptr() + (i % nuniq) * fbytes, 1)
+        if i % 30 == 0:
+            ctx.detect_enqueue(0)
+            hits, counts = ctx.detect_collect(cap=1 << 14)
+            best = ctx.best_faces(hits, counts, 1)[0]
+            if best["neighbors"] > 0 and best["confidence"] > -10:
+                ctx.camshift_init([[int(np.floor(best["x"])), int(np.floor(best["y"])), int(np.floor(best["width"])), int(np.floor(best["height"]))]])
+            out = best
+            lat["detect"].append((time.perf_counter() - t0) * 1e3)
+        else:
+            out = ctx.camshift_track(1, calc_angles=True)[0]
+            lat["track"].append((time.perf_counter() - t0) * 1e3)
+        return out
+
+    for i in range(max(a.warmup, 1) * 30 + 1):
+        frame(i)
+    lat = {"detect": [], "track": []}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    steps = a.steps if a.steps != 20 else 300
+    for i in range(steps):
+        last = frame(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        allv = np.array(lat["detect"] + lat["track"])
+        pct = lambda v, q: round(float(np.percentile(np.array(v), q)), 4) if len(v) else None  # noqa: E731
+        print(json.dumps({
+            "metric": "frames/sec streaming 1920x1080 feeds (detect every 30th frame, camshift between), end to end incl. PCIe",
+            "value": round(world * steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "C5: one 1920x1080 RGBA feed per GPU, host->GPU every frame, detect on frames 0,30,60,... + camshift.track otherwise",
+                       "feeds_per_gpu": 1, "width": W, "height": H, "parallelism": f"{world} feed(s), one per GPU, no collective"},
+            "latency_ms": {"p50": pct(allv, 50), "p99": pct(allv, 99), "detect_p50": pct(lat["detect"], 50), "detect_max": pct(lat["detect"], 100),
+                           "track_p50": pct(lat["track"], 50), "track_p99": pct(lat["track"], 99)},
+            "last_track": [float(last["x"]), float(last["y"]), float(last["width"]), float(last["height"])],
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def main():
@@ -62,6 +135,9 @@ def main():
     from headtrackr_amd import distributed as hd
     from headtrackr_amd import synth
     from headtrackr_amd.api import Context
+
+    if a.workload == "c5":
+        return stream_bench(a, torch, dist, rank, world, local)
 
     if a.workload == "c4":
         W, H, nf = 1280, 720, a.frames or 128
@@ -194,9 +270,16 @@ def main():
                      windows_per_s=round(float(sc[0]) / (dev_ms * 1e-3), 1),
                      hits_per_step=int(len(hits)), stage_in=[int(v) for v in sc[:6]])
 
-    # ---- CPU baseline: the oracle port, single thread, bounded sample of the same frames (rank 0, N = 1 only) ------
+    # ---- CPU baselines on the box's host cores (rank 0, N = 1 only), bounded samples of the same frames ------------------
+    #  * "reference": the UNMODIFIED reference JS, single-threaded Node (its own execution model), from oracle/_ref
+    #  * "port":      the plain-C oracle restatement, 1 thread
     cpu = None
+    cpu_port = None
     if rank == 0 and world == 1 and a.cpu_seconds > 0:
+        import shutil
+        import subprocess
+        import tempfile
+
         from oracle import ht_oracle as ho
 
         blob = ctx.cascade.blob
@@ -207,9 +290,26 @@ def main():
             ho.detect_raw(frames[done], blob)
             done += 1
         cdt = time.perf_counter() - t0
-        cpu = dict(value=round(done / cdt, 3), unit="frames/s", cores=1, kind="port",
-                   sample=f"first {done} of the {nf} {W}x{H} frames of this workload, oracle/ht_oracle.c detect (gray+pyramid+scan), 1 thread",
-                   host_cpus=os.cpu_count())
+        cpu_port = dict(value=round(done / cdt, 3), unit="frames/s", cores=1, kind="port",
+                        sample=f"first {done} of the {nf} {W}x{H} frames of this workload, oracle/ht_oracle.c detect (gray+pyramid+scan), 1 thread",
+                        host_cpus=os.cpu_count())
+        cpu = cpu_port
+        gz = os.path.join(ROOT, "oracle", "_ref", "headtrackr_ref.js.gz")
+        node = shutil.which("node")
+        if node and os.path.exists(gz):
+            try:
+                ns = min(nf, 64)
+                with tempfile.NamedTemporaryFile(suffix=".raw") as tf:
+                    frames[:ns].tofile(tf.name)
+                    r = subprocess.run([node, os.path.join(ROOT, "oracle", "ref_bench.js"), tf.name, str(ns), str(W), str(H), str(a.cpu_seconds)],
+                                       capture_output=True, text=True, timeout=a.cpu_seconds * 6 + 120)
+                j = json.loads(r.stdout.strip().splitlines()[-1])
+                cpu = dict(value=round(j["fps"], 3), unit="frames/s", cores=1, kind="reference",
+                           sample=f"first {j['frames']} of the {nf} {W}x{H} frames of this workload: unmodified reference JS (ccv.grayscale + ccv.detect_objects(..., 5, 1)) "
+                                  f"on oracle/canvas_shim.js, {j['node']} single thread, median {j['ms_median']:.1f} ms/frame, {100 * j['shim_fraction']:.0f}% of it inside the canvas shim",
+                           host_cpus=j["cpus"], cpu_model=j["cpu_model"])
+            except Exception as e:  # the port baseline stands in
+                cpu = dict(cpu_port, note=f"reference JS baseline unavailable: {e}")
 
     if rank == 0:
         line = {
@@ -222,7 +322,7 @@ def main():
                                     "c4": "C4: 1280x720 frames, 128 per GPU (1024 on 8 GPUs), full cascade detect + all-gather of best-face records"}[a.workload],
                        "frames_per_gpu": nf, "batches_in_flight": depth, "width": W, "height": H, "unique_frames": uniq, "frame_mix": "1/3 LCG noise, 1/3 smooth, 1/3 faces",
                        "parallelism": f"frames sharded over {world} GPU(s), all-gather of {nf}x64B records" if world > 1 else "1 GPU"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_port": cpu_port,
         }
         line.update(extra)
         print(json.dumps(line), flush=True)

@@ -87,6 +87,11 @@ class Context:
         self._check(self._lib.ht_upload_frames(self._h, frames.ctypes.data, n, w * h * 4))
         self.nframes = n
 
+    def upload_ptr(self, host_ptr: int, n: int, frame_stride: int | None = None):
+        """Like upload(), from a raw host pointer (e.g. pinned memory: the copy then runs at PCIe speed)."""
+        self._check(self._lib.ht_upload_frames(self._h, host_ptr, n, frame_stride or self.width * self.height * 4))
+        self.nframes = n
+
     def bind_device(self, dev_ptr: int, n: int, frame_stride: int | None = None):
         """Use n RGBA frames already resident in device memory (e.g. a torch cuda tensor's data_ptr())."""
         self._check(self._lib.ht_bind_frames_device(self._h, dev_ptr, n, frame_stride or self.width * self.height * 4))

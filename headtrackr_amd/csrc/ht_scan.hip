@@ -220,7 +220,52 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     uint32_t qoff = 0;                        // start of the live entries inside qbuf[cur]
     int cur = 0;
     bool pushed = (split >= nstages);
-    for (int s = 0; s < nstages; s++) {
+    // ---- stage 0, generated code, two windows per thread per iteration: every window of the tile runs it (74 % of
+    // them end here), so it gets its own loop: the two independent evaluations give the scheduler twice the LDS reads
+    // to keep in flight per wait.
+    int s_first = 0;
+    if (GEN && stop_stage != 0 && split > 0 && nstages > 1) {
+        const HtDevStage st0 = stages[0];
+        for (uint32_t base = 0; base < n_in; base += 2 * NT) {
+            uint32_t id[2], xx[2], yy[2], Fv[2];
+            bool valid[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t pos = base + u * NT + tid;
+                valid[u] = pos < n_in;
+                id[u] = valid[u] ? pos : 0u;
+                yy[u] = (id[u] * S.div_magic) >> 20;
+                xx[u] = id[u] - yy[u] * (uint32_t)S.tw2;
+                valid[u] = valid[u] && xx[u] < (uint32_t)tw;
+            }
+            ht_gen_stage_0_x2(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), lds + (valid[1] ? 2u * (yy[1] * PITCH0 + xx[1]) : 0u), Fv[0], Fv[1]);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                bool pass = valid[u] && Fv[u] >= HT_GEN_FMIN[0];
+                if (valid[u] && Fv[u] == HT_GEN_FTIE[0])  // exact tie: the sequential binary64 sum decides
+                    pass = !(eval_stage_lds(lds, 2u * (yy[u] * PITCH0 + xx[u]), feats + st0.first, st0.count) < st0.threshold);
+                const unsigned long long m = __ballot(pass);
+                if (m) {
+                    const uint32_t cnt = __popcll(m);
+                    const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    uint32_t b0 = 0;
+                    if (lane == 0) b0 = atomicAdd(&s_nout, cnt);
+                    b0 = __shfl(b0, 0, 64);
+                    if (pass) qbuf[cur ^ 1][b0 + pre] = (uint16_t)id[u];
+                }
+            }
+        }
+        if (tid == 0 && my_stats) atomicAdd(&my_stats[0], (unsigned long long)(uint32_t)(tw * th));
+        __syncthreads();
+        n_in = s_nout;
+        __syncthreads();
+        if (tid == 0) s_nout = 0;
+        cur ^= 1;
+        if (n_in == 0) return;
+        __syncthreads();
+        s_first = 1;
+    }
+    for (int s = s_first; s < nstages; s++) {
         if (s == stop_stage) return;  // measurement knob (HT_DEBUG_STOP_STAGE): results are incomplete when set
         const HtDevStage st = stages[s];
         // hand-off rule: from stage `split` on, survivors leave for k_scan_deep (one wavefront per window, features

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""tools/collect_profiles.py TAG — turns the gpurun_out/ of tools/gpu_final.sh into the committed summaries:
+profiles/<TAG>_<wl>_kernel_stats.csv (rocprofv3 --kernel-trace --stats), profiles/<TAG>_<wl>_pmc_per_launch.csv
+(counters averaged per launch and kernel), profiles/traffic.json (HBM bytes per launch, see its _note) and
+profiles/<TAG>_bench_<wl>.json (the bench lines)."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+short = {"k_gray_linear": "gray", "k_resample": "resample", "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep"}
+traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/gpu_pmc.sh): bytes = "
+           "(2*FETCH_SIZE + WRITE_SIZE)*1024.  On gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section); "
+           "calibrated here on k_gray_linear, whose traffic is known exactly (reads W*H*4, writes W*H per frame): see gray_check. "
+           "Averages per launch; k_resample is the mean over its 7 launches per step."}
+for wl in ("c2", "c4"):
+    ks = glob.glob(os.path.join(G, f"prof_{wl}", "**", "*kernel_stats.csv"), recursive=True)
+    if ks:
+        shutil.copy(ks[0], os.path.join(P, f"{tag}_{wl}_kernel_stats.csv"))
+    rows_out = []
+    per = collections.defaultdict(dict)
+    for d in sorted(glob.glob(os.path.join(G, f"pmc_{wl}_*"))):
+        fs = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if not fs:
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        disp = collections.defaultdict(set)
+        for r in csv.DictReader(open(fs[0])):
+            m = re.search(r"(k_\w+)", r["Kernel_Name"])
+            if not m:
+                continue
+            agg[m.group(1)][r["Counter_Name"]] += float(r["Counter_Value"])
+            disp[m.group(1)].add(r["Dispatch_Id"])
+        for k, v in agg.items():
+            for c, x in sorted(v.items()):
+                rows_out.append((k, len(disp[k]), c, round(x / len(disp[k]), 1)))
+                per[k][c] = x / len(disp[k])
+    if rows_out:
+        with open(os.path.join(P, f"{tag}_{wl}_pmc_per_launch.csv"), "w") as fh:
+            fh.write("kernel,launches,counter,value_per_launch\n")
+            for r in rows_out:
+                fh.write(",".join(map(str, r)) + "\n")
+    t = {}
+    for k, v in per.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v and k in short:
+            t[short[k]] = round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
+    if t:
+        traffic[wl] = t
+    bj = os.path.join(G, f"bench_{wl}.json")
+    if os.path.exists(bj):
+        shutil.copy(bj, os.path.join(P, f"{tag}_bench_{wl}.json"))
+for wl in ("c3", "c5"):
+    bj = os.path.join(G, f"bench_{wl}.json")
+    if os.path.exists(bj):
+        shutil.copy(bj, os.path.join(P, f"{tag}_bench_{wl}.json"))
+if len(traffic) > 1:
+    nf = {"c2": (256, 320, 240), "c4": (128, 1280, 720)}
+    traffic["gray_check"] = {wl: {"measured": traffic[wl].get("gray"), "known": nf[wl][0] * nf[wl][1] * nf[wl][2] * 5} for wl in traffic if wl in nf}
+    json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+print(sorted(os.listdir(P)))

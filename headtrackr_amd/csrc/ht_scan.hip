@@ -134,6 +134,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     __shared__ uint16_t qbuf[2][MAXWIN];
     __shared__ uint32_t s_nout;
     __shared__ uint32_t s_qbase;
+    __shared__ uint32_t s_F[64];  // sparse phase: per-survivor integer stage sums assembled from the 4 waves' slices
 
     // XCD-aware tile order: consecutive tiles (same frame / scale, shared halos) stay on one XCD's L2.
     const uint32_t nb = gridDim.x, chunk = nb >> 3;  // gridDim.x is a multiple of 8
@@ -299,6 +300,32 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         }
         const HtTileFeature *F = feats + st.first;
         const bool last = (s == nstages - 1);
+        if (GEN && NT == 256 && s < HT_GEN_STAGES && n_in <= 64u) {
+            // sparse phase: at most one wavefront of survivors left.  Instead of one wave walking the whole stage while
+            // three idle at the barrier, every wave takes the features k % 4 == wave for ALL survivors and the partial
+            // integer sums meet in LDS (exact: integer addition is order-free) — the stage takes a quarter of the time,
+            // so the tile's LDS and wave slots are released sooner.
+            const uint32_t wv = tid >> 6;
+            if (tid < 64u) s_F[tid] = 0u;
+            __syncthreads();
+            const bool valid = lane < n_in;
+            const uint32_t id = valid ? (uint32_t)qbuf[cur][qoff + lane] : 0u;
+            const uint32_t yy = (id * S.div_magic) >> 20, xx = id - yy * (uint32_t)S.tw2;
+            const uint32_t B = 2u * (yy * PITCH0 + xx);
+            const uint32_t part = ht_gen_stage_slice(s, (int)wv, lds + B);
+            if (valid && part) atomicAdd(&s_F[lane], part);
+            __syncthreads();
+            if (wv == 0) {
+                const uint32_t Fv = s_F[lane];
+                bool pass = valid && Fv >= HT_GEN_FMIN[s];
+                if (valid && Fv == HT_GEN_FTIE[s])  // exact tie with the threshold: let the sequential binary64 sum decide
+                    pass = !(eval_stage_lds(lds, B, F, st.count) < st.threshold);
+                const unsigned long long m = __ballot(pass);
+                const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (pass) qbuf[cur ^ 1][pre] = (uint16_t)id;
+                if (lane == 0) s_nout = (uint32_t)__popcll(m);
+            }
+        } else
         for (uint32_t base = 0; base < n_in; base += NT) {
             const uint32_t pos = base + tid;
             bool valid = pos < n_in;

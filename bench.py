@@ -268,7 +268,7 @@ def main():
                      path_hbm_frac=round(b_detect * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      windows_per_frame=int(ctx.windows_per_frame),
                      windows_per_s=round(float(sc[0]) / (dev_ms * 1e-3), 1),
-                     hits_per_step=int(len(hits)), stage_in=[int(v) for v in sc[:6]])
+                     hits_per_step=int(len(hits)), stage_in=[int(v) for v in sc])
 
     # ---- CPU baselines on the box's host cores (rank 0, N = 1 only), bounded samples of the same frames ------------------
     #  * "reference": the UNMODIFIED reference JS, single-threaded Node (its own execution model), from oracle/_ref

@@ -221,6 +221,7 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
     c->split_stage = std::min<uint32_t>(c->builtin_cascade ? 8u : 4u, c->nstages);
     if ((st = upload_cascade(c)) != HT_OK) return bail(st);
+    if ((st = ht_scan_pack_deep(c)) != HT_OK) return bail(st);
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), sizeof(HtCounters) + (size_t)HT_PINNED_HITS * sizeof(ht_hit), hipHostMallocDefault) != hipSuccess ||
         hipMalloc(&c->d_stats, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS) != hipSuccess ||
         hipMalloc(&c->d_counters, sizeof(HtCounters)) != hipSuccess ||
@@ -257,6 +258,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_tile_feats) (void)hipFree(c->d_tile_feats);
     if (c->d_deep_feats) (void)hipFree(c->d_deep_feats);
     if (c->d_patch_feats) (void)hipFree(c->d_patch_feats);
+    if (c->d_packed_feats) (void)hipFree(c->d_packed_feats);
     if (c->d_stages) (void)hipFree(c->d_stages);
     if (c->d_frames_own) (void)hipFree(c->d_frames_own);
     if (c->d_hits) (void)hipFree(c->d_hits);

@@ -57,6 +57,15 @@ struct alignas(16) HtPatchFeature {
 };
 static_assert(sizeof(HtPatchFeature) == 64, "HtPatchFeature");
 
+// Deep kernel, LDS-resident form: 32-byte record, the whole tail of the cascade (stages >= split) is copied into LDS once
+// per workgroup.  Usable when every feature has <= 5 points per polarity and |alpha * 1e8| < 2^31 (decimal cascade).
+struct alignas(16) HtPackedFeature {
+    uint16_t off[10];  // p0..p4, n0..n4 patch offsets (unused slots repeat slot 0 of their polarity)
+    int32_t a0i, a1i;  // alpha * 1e8; the binary64 alpha is recovered exactly as (double)a / 1e8
+    uint32_t pad;
+};
+static_assert(sizeof(HtPackedFeature) == 32, "HtPackedFeature");
+
 struct HtDevStage {
     uint32_t first, count;
     uint32_t maxpts;  // max(np, nn) over the stage's features
@@ -153,6 +162,8 @@ struct ht_ctx {
     HtTileFeature *d_tile_feats = nullptr;
     HtDeepFeature *d_deep_feats = nullptr;
     HtPatchFeature *d_patch_feats = nullptr;
+    HtPackedFeature *d_packed_feats = nullptr;  // features of stages >= split_stage (index 0 = first feature of that stage)
+    uint32_t packed_count = 0, packed_first = 0; // number of packed features / global index of the first one (0 count = unusable)
     bool builtin_cascade = false;  // blob == the cascade ht_cascade_gen.inc was generated from
     uint32_t deep_bias = 1;        // tile kernel hands survivors to the deep kernel when n*bias*ceil(count/64) <= count
                                    // (measured on C2/C4: split 8 + bias 0..1 is the optimum, profiles/r01_sweeps.txt)
@@ -174,7 +185,7 @@ struct ht_ctx {
     std::vector<HtScanScale> h_scales;
     HtScanScale *d_scales = nullptr;
     uint32_t tiles_per_frame = 0;
-    int rs_rpt = 2;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
+    int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
 
     // frames
     uint8_t *d_frames_own = nullptr;
@@ -233,6 +244,7 @@ ht_status ht_launch_pyramid(ht_ctx *ctx, uint32_t flags);   // ht_pyramid.hip
 ht_status ht_launch_scan(ht_ctx *ctx, uint32_t flags);      // ht_scan.hip
 ht_status ht_scan_tile_tables(ht_ctx *ctx);                 // ht_scan.hip: LDS-offset feature table
 ht_status ht_scan_plan_tiles(ht_ctx *ctx);
-bool ht_scan_is_builtin_cascade(const uint8_t *blob, size_t len);  // ht_scan.hip                  // ht_scan.hip: per-scale tiling for the geometry
+bool ht_scan_is_builtin_cascade(const uint8_t *blob, size_t len);  // ht_scan.hip
+ht_status ht_scan_pack_deep(ht_ctx *ctx);                           // ht_scan.hip: LDS-resident table for stages >= split_stage                  // ht_scan.hip: per-scale tiling for the geometry
 ht_status ht_launch_gray_inplace(ht_ctx *ctx, uint8_t *d_rgba, int n, size_t stride);  // ht_pyramid.hip
 ht_status ht_launch_whitebalance(ht_ctx *ctx, double *d_out);                            // ht_pyramid.hip

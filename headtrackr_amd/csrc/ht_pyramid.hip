@@ -120,17 +120,17 @@ __device__ __forceinline__ RsTap rs_tap(int i, double r, int s, int origin) {
 }
 
 // 4 destination pixels of one row from two source rows (r0/r1 either in LDS or in HBM: two instantiations, so the loads
-// are ds_read_u8 / global_load_ubyte rather than flat loads)
+// are ds_read_u8 / global_load_ubyte rather than flat loads).  The 4 column taps live in registers (loaded once per thread,
+// reused for every row the thread produces).
 template <typename PTR>
-__device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap *s_col, const RsTap &ry, int cbase, int xoff, int npx) {
+__device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap (&cx)[4], const RsTap &ry, int xoff, int npx) {
     uint32_t o = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (k < npx) {
-            const RsTap cx = s_col[cbase + k];
-            const int ia = cx.a - xoff, ib = cx.b - xoff;
-            const double top = __dadd_rn(__dmul_rn((double)r0[ia], cx.u), __dmul_rn((double)r0[ib], cx.t));
-            const double bot = __dadd_rn(__dmul_rn((double)r1[ia], cx.u), __dmul_rn((double)r1[ib], cx.t));
+            const int ia = cx[k].a - xoff, ib = cx[k].b - xoff;
+            const double top = __dadd_rn(__dmul_rn((double)r0[ia], cx[k].u), __dmul_rn((double)r0[ib], cx[k].t));
+            const double bot = __dadd_rn(__dmul_rn((double)r1[ia], cx[k].u), __dmul_rn((double)r1[ib], cx[k].t));
             const double vv = __dadd_rn(__dmul_rn(top, ry.u), __dmul_rn(bot, ry.t));
             const int q = (int)__builtin_rint(vv);  // Uint8ClampedArray: round half to even (values are within [0,255])
             o |= (uint32_t)q << (8 * k);
@@ -186,21 +186,27 @@ __global__ __launch_bounds__(256) void k_resample(const HtResampleJob *__restric
                 if (i < SR * RW) *reinterpret_cast<uint32_t *>(&s_src[i * 4]) = v[k];
             }
             __syncthreads();
+            RsTap cx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cx[k] = s_col[min(x0 - X0 + k, ncols - 1)];
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
                 const int y = yt + 16 * q;
                 if (y < J.dh && npx > 0) {
                     const RsTap ry = s_row[y - Y0];
-                    o[q] = rs_pixels4<const uint8_t *>(s_src + (ry.a - ya) * RS_SP, s_src + (ry.b - ya) * RS_SP, s_col, ry, x0 - X0, xa, npx);
+                    o[q] = rs_pixels4<const uint8_t *>(s_src + (ry.a - ya) * RS_SP, s_src + (ry.b - ya) * RS_SP, cx, ry, xa, npx);
                 }
             }
         } else {
+            RsTap cx[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) cx[k] = s_col[min(x0 - X0 + k, ncols - 1)];
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
                 const int y = yt + 16 * q;
                 if (y < J.dh && npx > 0) {
                     const RsTap ry = s_row[y - Y0];
-                    o[q] = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * J.src_stride, src + (size_t)ry.b * J.src_stride, s_col, ry, x0 - X0, 0, npx);
+                    o[q] = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * J.src_stride, src + (size_t)ry.b * J.src_stride, cx, ry, 0, npx);
                 }
             }
         }

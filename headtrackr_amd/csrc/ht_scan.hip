@@ -456,21 +456,27 @@ __device__ __forceinline__ bool patch_fire(const uint8_t *patch, const HtPatchFe
     return pmin > nmax;
 }
 
+// sum += sel[0] + sel[1] + ... + sel[nn-1] in lane order, sequential binary64 adds (the reference's order).  Each lane holds
+// the alpha its own feature selected; v_readlane broadcasts them one by one, so the only loop-carried dependency is the
+// add itself (fetching the alphas from memory inside this chain cost ~50 us per full survivor).
+__device__ __forceinline__ double seq_add_lanes(double sum, double sel, uint32_t nn) {
+    const int lo = __double2loint(sel), hi = __double2hiint(sel);
+    for (uint32_t t = 0; t < nn; t++) {
+        const int l = __builtin_amdgcn_readlane(lo, (int)t), h = __builtin_amdgcn_readlane(hi, (int)t);
+        sum = __dadd_rn(sum, __hiloint2double(h, l));
+    }
+    return sum;
+}
+
 // sequential binary64 stage sum in the reference's order: fire bits in parallel, adds in order (all lanes redundantly)
 __device__ __forceinline__ double patch_stage_sum_exact(const uint8_t *patch, const HtPatchFeature *__restrict__ F, uint32_t count,
                                                         uint32_t maxpts, uint32_t lane) {
     double sum = 0.0;
     for (uint32_t kb = 0; kb < count; kb += 64) {
         const uint32_t k = kb + lane;
-        bool fire = false;
-        if (k < count) fire = patch_fire(patch, &F[k], maxpts);
-        const unsigned long long m = __ballot(fire);
-        const uint32_t nn = min(64u, count - kb);
-        for (uint32_t t = 0; t < nn; t++) {
-            const uint4 A = *reinterpret_cast<const uint4 *>(&F[kb + t].a0);  // uniform: scalar load of {a0, a1}
-            const bool f1 = (m >> t) & 1ull;
-            sum = __dadd_rn(sum, __hiloint2double((int)(f1 ? A.w : A.y), (int)(f1 ? A.z : A.x)));
-        }
+        double sel = 0.0;
+        if (k < count) sel = patch_fire(patch, &F[k], maxpts) ? F[k].a1 : F[k].a0;
+        sum = seq_add_lanes(sum, sel, min(64u, count - kb));
     }
     return sum;
 }
@@ -704,6 +710,273 @@ __global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__
     }
 }
 
+// ---- deep kernel, workgroup form ---------------------------------------------------------------------------------------
+// One WORKGROUP (4 wavefronts) per surviving window.  k_scan_deep's run time is the critical path of a single face window
+// (33 sequential 64-feature chunks from stage 8 to 15, each waiting on L2 for its feature records) no matter how few
+// windows there are; here a stage's features are spread over 256 lanes, so stage 15 is 3 steps instead of 9 and the whole
+// chain ~12 steps instead of 33.  Partial integer sums meet in LDS (exact, order-free); the sequential binary64 pass of
+// the last stage / of an exact tie uses the 4 waves' ballot masks.
+__global__ __launch_bounds__(256) void k_scan_deep_wg(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+                                                      const HtDevLevel *__restrict__ levels, int next,
+                                                      const HtPatchFeature *__restrict__ feats, const HtDevStage *__restrict__ stages,
+                                                      int nstages, int use_int, const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
+                                                      ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr,
+                                                      unsigned long long *__restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) uint8_t patch[PATCH_BYTES];
+    __shared__ long long s_part[4];
+    __shared__ unsigned long long s_mask[16 * 4];  // fire bits of up to 16 x 256 features
+    __shared__ double s_sum;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    unsigned long long *my_stats = stats ? stats + (size_t)(blockIdx.x & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
+    const uint32_t n = min(ctr->nqueue, queue_cap);
+    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
+        const HtQueueEntry ent = queue[e];
+        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
+                     (uint32_t)ent.y)
+        int j = (int)ent.pad;
+        HtDevStage st = stages[j];
+        PatchFeatRegs cur;
+        if (tid < st.count) cur = load_feat(feats + st.first + tid);
+        {   // window patch: 288 halfwords of plane 0, 144 bytes of plane 1, 36 bytes of plane 2 (all issued together)
+            uint32_t pa0 = 0, pa1 = 0, pb = 0, pc = 0;
+            {
+                const uint32_t r = tid / 12u, c2 = (tid - r * 12u) * 2u;
+                pa0 = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);  // tid < 256 <= 288
+            }
+            if (tid < 32u) {
+                const uint32_t i = tid + 256u, r = i / 12u, c2 = (i - r * 12u) * 2u;
+                pa1 = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);
+            }
+            if (tid >= 64u && tid < 208u) {
+                const uint32_t i = tid - 64u, r = i / 12u, c = i - r * 12u;
+                pb = fb[o1 + r * (uint32_t)s1 + c];
+            }
+            if (tid >= 208u && tid < 244u) {
+                const uint32_t i = tid - 208u, r = i / 6u, c = i - r * 6u;
+                pc = fb[o2 + r * (uint32_t)s2 + c];
+            }
+            __syncthreads();  // the previous window's readers are done with the patch
+            *reinterpret_cast<uint16_t *>(&patch[2u * tid]) = (uint16_t)pa0;
+            if (tid < 32u) *reinterpret_cast<uint16_t *>(&patch[2u * (tid + 256u)]) = (uint16_t)pa1;
+            if (tid >= 64u && tid < 208u) patch[PATCH1 + tid - 64u] = (uint8_t)pb;
+            if (tid >= 208u && tid < 244u) patch[PATCH2 + tid - 208u] = (uint8_t)pc;
+        }
+        __syncthreads();
+        bool alive = true;
+        double conf = 0.0;
+        uint32_t kb = 0;
+        long long acc = 0;
+        while (true) {
+            const bool stage_ends = kb + 256u >= st.count;
+            int jn = j;
+            uint32_t kbn = kb + 256u;
+            HtDevStage stn = st;
+            if (stage_ends) {
+                jn = j + 1;
+                kbn = 0;
+                if (jn < nstages) stn = stages[jn];
+            }
+            PatchFeatRegs nxt = cur;
+            if (jn < nstages && kbn + tid < stn.count) nxt = load_feat(feats + stn.first + kbn + tid);  // one chunk ahead
+            if (kb == 0 && tid == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
+            if (use_int && kb + tid < st.count) acc += fire_regs(patch, cur, st.maxpts) ? cur.a1i : cur.a0i;
+            if (stage_ends) {
+                bool need_exact = true;
+                if (use_int) {
+                    const long long w = wave_sum_i64(acc);
+                    acc = 0;
+                    if (lane == 0) s_part[wv] = w;
+                    __syncthreads();
+                    const long long Ssum = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+                    __syncthreads();
+                    if (Ssum < st.thri) {  // exact, order-free
+                        alive = false;
+                        break;
+                    }
+                    need_exact = (Ssum == st.thri) || (j == nstages - 1);
+                }
+                if (need_exact) {  // sequential binary64 sum in the reference's order (ccv.js:186-221)
+                    const HtPatchFeature *F = feats + st.first;
+                    const uint32_t nch = (st.count + 255u) >> 8;
+                    for (uint32_t c = 0; c < nch && c < 16u; c++) {
+                        const uint32_t k = c * 256u + tid;
+                        bool fire = false;
+                        if (k < st.count) fire = patch_fire(patch, &F[k], st.maxpts);
+                        const unsigned long long mm = __ballot(fire);
+                        if (lane == 0) s_mask[c * 4 + wv] = mm;
+                    }
+                    __syncthreads();
+                    if (wv == 0) {
+                        double sum = 0.0;
+                        for (uint32_t k = 0; k < st.count; k++) {
+                            const uint4 A = *reinterpret_cast<const uint4 *>(&F[k].a0);  // uniform: {a0, a1}
+                            const bool f1 = (s_mask[k >> 6] >> (k & 63u)) & 1ull;
+                            sum = __dadd_rn(sum, __hiloint2double((int)(f1 ? A.w : A.y), (int)(f1 ? A.z : A.x)));
+                        }
+                        if (lane == 0) s_sum = sum;
+                    }
+                    __syncthreads();
+                    const double sum = s_sum;
+                    __syncthreads();
+                    if (sum < st.threshold) {  // ccv.js:222
+                        alive = false;
+                        break;
+                    }
+                    conf = sum;
+                }
+                if (jn >= nstages) break;
+            }
+            j = jn;
+            kb = kbn;
+            st = stn;
+            cur = nxt;
+        }
+        if (alive && tid == 0) {
+            if (my_stats) atomicAdd(&my_stats[nstages], 1ull);
+            const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
+            if (pos < hit_cap) {
+                ht_hit h;
+                h.frame = ent.frame;
+                h.x = ent.x;
+                h.y = ent.y;
+                h.scale = ent.scale;
+                h.q = ent.q;
+                h.reserved0 = 0;
+                h.reserved1 = 0;
+                h.sum = conf;
+                hits[pos] = h;
+            }
+        }
+    }
+}
+
+// ---- deep kernel, LDS-resident feature table -------------------------------------------------------------------------------
+// k_scan_deep re-reads every stage's 64-byte feature records from L2 for every window: ~100k chunk-steps x 4 KB = 400 MB per
+// C2 batch, which is what it spends its time on.  Here the tail of the cascade (stages >= split, 1868 features x 32 B = 60 KB)
+// is copied into LDS once per workgroup (one 1024-thread workgroup per CU); every wavefront then owns a window at a time
+// exactly like k_scan_deep, but feature records and pixels both come from LDS.
+constexpr uint32_t DEEP_LDS_TABLE_BYTES = 64 * 1024;
+constexpr int DEEPL_WAVES = 16;
+
+__device__ __forceinline__ bool packed_fire(const uint8_t *patch, const uint4 A, const uint32_t B0) {
+    // A = off[0..7], B0 = off[8..9]
+    const uint32_t p0 = A.x & 0xffffu, p1 = A.x >> 16, p2 = A.y & 0xffffu, p3 = A.y >> 16, p4 = A.z & 0xffffu;
+    const uint32_t n0 = A.z >> 16, n1 = A.w & 0xffffu, n2 = A.w >> 16, n3 = B0 & 0xffffu, n4 = B0 >> 16;
+    const uint32_t pmin = min(min(min((uint32_t)patch[p0], (uint32_t)patch[p1]), min((uint32_t)patch[p2], (uint32_t)patch[p3])), (uint32_t)patch[p4]);
+    const uint32_t nmax = max(max(max((uint32_t)patch[n0], (uint32_t)patch[n1]), max((uint32_t)patch[n2], (uint32_t)patch[n3])), (uint32_t)patch[n4]);
+    return pmin > nmax;
+}
+
+__global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+                                                                   const HtDevLevel *__restrict__ levels, int next,
+                                                                   const HtPackedFeature *__restrict__ packed, uint32_t packed_count,
+                                                                   uint32_t packed_first, const HtDevStage *__restrict__ stages, int nstages,
+                                                                   const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
+                                                                   ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr,
+                                                                   unsigned long long *__restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+    uint4 *tab = reinterpret_cast<uint4 *>(dyn_lds);                       // packed_count x 32 B
+    uint8_t *patches = dyn_lds + (size_t)packed_count * sizeof(HtPackedFeature);  // DEEPL_WAVES x PATCH_BYTES
+    const uint32_t n = min(ctr->nqueue, queue_cap);
+    if (blockIdx.x * DEEPL_WAVES >= n) return;  // nothing for this workgroup: skip the table copy
+    for (uint32_t i = threadIdx.x; i < packed_count * 2u; i += blockDim.x) tab[i] = reinterpret_cast<const uint4 *>(packed)[i];
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint8_t *patch = patches + wv * PATCH_BYTES;
+    const uint32_t wave = blockIdx.x * DEEPL_WAVES + wv, nwaves = gridDim.x * DEEPL_WAVES;
+    unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
+    for (uint32_t e = wave; e < n; e += nwaves) {
+        const HtQueueEntry ent = queue[e];
+        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
+                     (uint32_t)ent.y)
+        {
+            uint32_t pa[5], pb[3], pc = 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t i = lane + 64u * k, r = i / 12u, c2 = (i - r * 12u) * 2u;
+                pa[k] = 0;
+                if (i < 288u) pa[k] = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t i = lane + 64u * k, r = i / 12u, c = i - r * 12u;
+                pb[k] = 0;
+                if (i < 144u) pb[k] = fb[o1 + r * (uint32_t)s1 + c];
+            }
+            if (lane < 36u) {
+                const uint32_t r = lane / 6u, c = lane - r * 6u;
+                pc = fb[o2 + r * (uint32_t)s2 + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const uint32_t i = lane + 64u * k;
+                if (i < 288u) *reinterpret_cast<uint16_t *>(&patch[2u * i]) = (uint16_t)pa[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const uint32_t i = lane + 64u * k;
+                if (i < 144u) patch[PATCH1 + i] = (uint8_t)pb[k];
+            }
+            if (lane < 36u) patch[PATCH2 + lane] = (uint8_t)pc;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        bool alive = true;
+        double conf = 0.0;
+        for (int j = (int)ent.pad; j < nstages; j++) {
+            const HtDevStage st = stages[j];
+            const uint32_t base = st.first - packed_first;  // index of the stage's first record in the LDS table
+            if (lane == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
+            long long acc = 0;
+            for (uint32_t k = lane; k < st.count; k += 64) {
+                const uint4 A = tab[(base + k) * 2u], Bq = tab[(base + k) * 2u + 1u];
+                acc += packed_fire(patch, A, Bq.x) ? (long long)(int32_t)Bq.z : (long long)(int32_t)Bq.y;
+            }
+            const long long Ssum = wave_sum_i64(acc);
+            if (Ssum < st.thri) {  // sum < threshold decided exactly, independent of summation order
+                alive = false;
+                break;
+            }
+            if (Ssum == st.thri || j == nstages - 1) {
+                // sequential binary64 sum in the reference's order (ccv.js:186-221): fire bits by ballot, adds in feature order
+                double sum = 0.0;
+                for (uint32_t kb = 0; kb < st.count; kb += 64) {
+                    const uint32_t k = kb + lane;
+                    double sel = 0.0;
+                    if (k < st.count) {
+                        const uint4 A = tab[(base + k) * 2u], Bq = tab[(base + k) * 2u + 1u];
+                        const int32_t ai = packed_fire(patch, A, Bq.x) ? (int32_t)Bq.z : (int32_t)Bq.y;
+                        sel = (double)ai / 1e8;  // == alpha exactly (checked when the table was packed)
+                    }
+                    sum = seq_add_lanes(sum, sel, min(64u, st.count - kb));
+                }
+                if (sum < st.threshold) {  // ccv.js:222
+                    alive = false;
+                    break;
+                }
+                conf = sum;
+            }
+        }
+        if (alive && lane == 0) {
+            if (my_stats) atomicAdd(&my_stats[nstages], 1ull);
+            const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
+            if (pos < hit_cap) {
+                ht_hit h;
+                h.frame = ent.frame;
+                h.x = ent.x;
+                h.y = ent.y;
+                h.scale = ent.scale;
+                h.q = ent.q;
+                h.reserved0 = 0;
+                h.reserved1 = 0;
+                h.sum = conf;
+                hits[pos] = h;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ----------------------------------------------------------------------------------------------------------------
 // simple kernel: one thread per window, every stage, straight from HBM (independent cross-check of the tiled path)
 
@@ -825,6 +1098,51 @@ ht_status ht_scan_tile_tables(ht_ctx *c) {
     return HT_OK;
 }
 
+// LDS-resident deep table: features of stages [split, nstages) in HtPackedFeature form; leaves packed_count = 0 when the
+// cascade does not fit the format (then k_scan_deep is used)
+ht_status ht_scan_pack_deep(ht_ctx *c) {
+    if (c->d_packed_feats) (void)hipFree(c->d_packed_feats), c->d_packed_feats = nullptr;
+    c->packed_count = 0;
+    if (!c->decimal_alphas || c->split_stage >= c->nstages || c->cw != 24 || c->ch != 24) return HT_OK;
+    const uint32_t first = c->h_stages[c->split_stage].first;
+    const uint32_t n = c->nfeat - first;
+    if (n == 0 || n * sizeof(HtPackedFeature) > DEEP_LDS_TABLE_BYTES) return HT_OK;
+    std::vector<HtPackedFeature> pk(n);
+    for (uint32_t k = 0; k < n; k++) {
+        const HtBlobFeature &f = c->h_feats[first + k];
+        HtPackedFeature &t = pk[k];
+        std::memset(&t, 0, sizeof(t));
+        auto poff = [&](int x, int y, int z) -> uint16_t {
+            if (z == 0) return (uint16_t)(y * 24 + x);
+            if (z == 1) return (uint16_t)(PATCH1 + y * 12 + x);
+            return (uint16_t)(PATCH2 + y * 6 + x);
+        };
+        int np = 0, nn = 0;
+        for (int q = 0; q < f.size; q++) {
+            if (f.pz[q] >= 0) {
+                if (np >= 5) return HT_OK;
+                t.off[np++] = poff(f.px[q], f.py[q], f.pz[q]);
+            }
+            if (f.nz[q] >= 0) {
+                if (nn >= 5) return HT_OK;
+                t.off[5 + nn++] = poff(f.nx[q], f.ny[q], f.nz[q]);
+            }
+        }
+        for (int q = np; q < 5; q++) t.off[q] = t.off[0];
+        for (int q = nn; q < 5; q++) t.off[5 + q] = t.off[5];
+        const double s0 = f.alpha[0] * 1e8, s1 = f.alpha[1] * 1e8;
+        if (!(std::fabs(s0) < 2.0e9) || !(std::fabs(s1) < 2.0e9)) return HT_OK;
+        t.a0i = (int32_t)llround(s0);
+        t.a1i = (int32_t)llround(s1);
+        if ((double)t.a0i / 1e8 != f.alpha[0] || (double)t.a1i / 1e8 != f.alpha[1]) return HT_OK;
+    }
+    HT_HIP(c, hipMalloc(&c->d_packed_feats, pk.size() * sizeof(HtPackedFeature)));
+    HT_HIP(c, hipMemcpy(c->d_packed_feats, pk.data(), pk.size() * sizeof(HtPackedFeature), hipMemcpyHostToDevice));
+    c->packed_count = n;
+    c->packed_first = first;
+    return HT_OK;
+}
+
 // true iff blob is byte-identical to the cascade ht_cascade_gen.inc was generated from (FNV-1a 64 + length)
 bool ht_scan_is_builtin_cascade(const uint8_t *blob, size_t len) {
     if (len != HT_GEN_CASCADE_LEN) return false;
@@ -915,7 +1233,22 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     if (split < (int)c->nstages) {
         HtProfScope ps(c, "scan_deep");
         const char *dv = getenv("HT_DEBUG_DEEP_V");
-        if (dv && atoi(dv) == 1)
+        const int deep_v = dv ? atoi(dv) : 4;
+        if (deep_v == 4 && c->packed_count && c->h_stages[split].first >= c->packed_first) {
+            const size_t lds = (size_t)c->packed_count * sizeof(HtPackedFeature) + (size_t)DEEPL_WAVES * PATCH_BYTES;
+            static bool attr_set = false;
+            if (!attr_set) {
+                HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_deep_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_scan_deep_lds, dim3(256), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
+                               c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, c->d_queue, c->queue_capacity,
+                               c->d_hits, c->hit_capacity, c->d_counters, stats);
+        } else if (dv && atoi(dv) == 3)
+            hipLaunchKernelGGL(k_scan_deep_wg, dim3(4096), dim3(256), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
+                               c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
+                               c->hit_capacity, c->d_counters, stats);
+        else if (dv && atoi(dv) == 1)
             hipLaunchKernelGGL(k_scan_deep_v1, dim3(2048), dim3(64 * DEEP_WAVES), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                                c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
                                c->hit_capacity, c->d_counters, stats);

@@ -242,27 +242,39 @@ def main():
         kt = ctx.kernel_times(reset=True)
         ctx.profile(False)
         per_step = {k: v["ms"] / psteps for k, v in kt.items()}
-        dom = max(per_step, key=per_step.get)
+        per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items()}
+        # "dominant kernel" = the longest single launch (the unit the roofline formula is written in).  k_resample runs 7
+        # dependent launches per step, each over a different slice of the pyramid; its total per step is listed in
+        # kernel_ms_per_step and its own-bytes roofline in kernel_rooflines.
+        dom = max(per_launch, key=per_launch.get)
         P = ctx.pyramid_bytes_per_frame
         b_detect = 4 * W * H + 2 * P  # read RGBA once, write each gray plane once, read it once in the scan
         launches_per_step = kt[dom]["launches"] / psteps
-        avg_launch_ms = kt[dom]["ms"] / kt[dom]["launches"]
+        avg_launch_ms = per_launch[dom]
         achieved = b_detect * nf / launches_per_step / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
+        all_traffic = {}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tf):
             try:
-                traffic = json.load(open(tf)).get(a.workload, {}).get(dom)
+                all_traffic = json.load(open(tf)).get(a.workload, {})
+                traffic = all_traffic.get(dom)
             except Exception:
                 traffic = None
         roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                         frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
                         algorithmic_bytes_per_frame=b_detect, avg_launch_ms=round(avg_launch_ms, 5))
+        # each kernel against its OWN algorithmic bytes (per step): gray 5*W*H, pyramid build 2*(P - W*H) (every derived plane
+        # written once, its source read once), tile scan P (every plane read once)
+        own = {"gray": 5 * W * H * nf, "resample": 2 * (P - W * H) * nf, "scan_tiles": P * nf}
+        kernel_rooflines = {k: dict(own_bytes_per_step=own[k], gbs=round(own[k] / (per_step[k] * 1e-3) / 1e9, 1),
+                                    frac=round(own[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                    hbm_traffic_per_launch=all_traffic.get(k)) for k in own if k in per_step}
         dev_ms = sum(per_step.values())
         ctx.detect_enqueue(a.flags | 16)  # one extra untimed pass with HT_SCAN_STATS for the survival curve
         ctx.detect_collect(cap=1 << 16)
         sc = ctx.stage_counts()
-        extra = dict(kernel_ms_per_step={k: round(v, 5) for k, v in per_step.items()},
+        extra = dict(kernel_ms_per_step={k: round(v, 5) for k, v in per_step.items()}, kernel_rooflines=kernel_rooflines,
                      device_ms_per_step=round(dev_ms, 5),
                      path_hbm_gbs=round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2),
                      path_hbm_frac=round(b_detect * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

@@ -37,7 +37,8 @@ constexpr int TXH = 64;                 // tile width  in half-window steps X'
 #define HT_TILE_TYH 32
 #endif
 #ifndef HT_TILE_WPS
-#define HT_TILE_WPS (HT_TILE_NT / 64)
+#define HT_TILE_WPS 5  // waves per SIMD the register allocator must leave room for: 5 workgroups per CU (96 VGPRs, 30.5 KB LDS each);
+                       // measured: 4 -> 5 is -15 % on the tile kernel, 6..8 (with smaller tiles) no further gain
 #endif
 constexpr int TYH = HT_TILE_TYH;        // tile height in half-window steps Y'
 #ifndef HT_TILE_NT
@@ -131,7 +132,15 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                                                    uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
                                                    HtCounters *__restrict__ ctr, unsigned long long *__restrict__ stats) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TILE_BYTES];
-    __shared__ uint16_t qbuf[2][MAXWIN];
+#ifndef HT_TILE_INPLACE
+#define HT_TILE_INPLACE 1
+#endif
+    // survivor queue(s) of window ids.  In-place mode: ONE queue, stage s compacts it onto itself (a thread reads its entry,
+    // the workgroup synchronises, then survivors are written to the front) — 4 KB less LDS per workgroup = 5 instead of
+    // 4 workgroups per CU.
+    constexpr int NQ = HT_TILE_INPLACE ? 1 : 2;
+    constexpr int QX = HT_TILE_INPLACE ? 0 : 1;  // cur ^ QX = index of the output queue
+    __shared__ uint16_t qbuf[NQ][MAXWIN];
     __shared__ uint32_t s_nout;
     __shared__ uint32_t s_qbase;
     __shared__ uint32_t s_F[64];  // sparse phase: per-survivor integer stage sums assembled from the 4 waves' slices
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                     uint32_t b0 = 0;
                     if (lane == 0) b0 = atomicAdd(&s_nout, cnt);
                     b0 = __shfl(b0, 0, 64);
-                    if (pass) qbuf[cur ^ 1][b0 + pre] = (uint16_t)id[u];
+                    if (pass) qbuf[cur ^ QX][b0 + pre] = (uint16_t)id[u];
                 }
             }
         }
@@ -261,7 +270,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         n_in = s_nout;
         __syncthreads();
         if (tid == 0) s_nout = 0;
-        cur ^= 1;
+        cur ^= QX;
         if (n_in == 0) return;
         __syncthreads();
         s_first = 1;
@@ -322,7 +331,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                     pass = !(eval_stage_lds(lds, B, F, st.count) < st.threshold);
                 const unsigned long long m = __ballot(pass);
                 const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (pass) qbuf[cur ^ 1][pre] = (uint16_t)id;
+                if (pass) qbuf[cur ^ QX][pre] = (uint16_t)id;
                 if (lane == 0) s_nout = (uint32_t)__popcll(m);
             }
         } else
@@ -331,6 +340,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             bool valid = pos < n_in;
             uint32_t id = 0;
             if (valid) id = (s == 0) ? pos : (uint32_t)qbuf[cur][qoff + pos];
+            if (HT_TILE_INPLACE && s > 0) __syncthreads();  // every entry of this chunk is in a register before survivors overwrite the queue
             const uint32_t yy = (id * S.div_magic) >> 20, xx = id - yy * (uint32_t)S.tw2;
             valid = valid && xx < (uint32_t)tw;
             const uint32_t B = 2u * (yy * PITCH0 + xx);
@@ -354,7 +364,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 if (!last) {
                     if (lane == 0) b0 = atomicAdd(&s_nout, cnt);
                     b0 = __shfl(b0, 0, 64);
-                    if (pass) qbuf[cur ^ 1][b0 + pre] = (uint16_t)id;
+                    if (pass) qbuf[cur ^ QX][b0 + pre] = (uint16_t)id;
                 } else {
                     if (lane == 0) b0 = atomicAdd(&ctr->nhits, cnt);
                     b0 = __shfl(b0, 0, 64);
@@ -380,7 +390,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         n_in = s_nout;
         __syncthreads();
         if (tid == 0) s_nout = 0;
-        cur ^= 1;
+        cur ^= QX;
         qoff = 0;
         if (n_in == 0) return;
         // s_nout reset is ordered before its next use by the __syncthreads at the end of the next stage's loop body:

@@ -247,6 +247,7 @@ static void free_geometry(ht_ctx *c) {
     c->d_gens.clear();
     c->h_gens.clear();
     c->gen_blocks.clear();
+    c->gen_rpt.clear();
     c->h_scales.clear();
 }
 
@@ -394,12 +395,19 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
     c->d_gens.assign(ngen, nullptr);
     c->d_gen_blocks.assign(ngen, nullptr);
     c->gen_blocks.assign(ngen, 0);
+    c->gen_rpt.assign(ngen, c->rs_rpt);
     for (int g = 1; g < ngen; g++) {
+        // tile height per generation: 64 x 64 destination pixels for the big levels, smaller tiles where the levels are
+        // small (a 40 x 30 level fills 29 % of a 64 x 64 tile but 59 % of a 64 x 32 one)
+        int maxh = 0;
+        for (auto &j : c->h_gens[g]) maxh = std::max(maxh, j.ch);
+        if (!getenv("HT_DEBUG_RS_RPT")) c->gen_rpt[g] = maxh >= 160 ? 4 : (maxh >= 48 ? 2 : 1);
+        const int rpt = c->gen_rpt[g];
         uint32_t b = 0;
         for (auto &j : c->h_gens[g]) {
             j.block_begin = b;
             j.blocks_x = (uint32_t)((j.cw + 63) / 64);   // k_resample tile: 64 x (16 * rs_rpt) destination pixels
-            b += j.blocks_x * (uint32_t)((j.ch + 16 * c->rs_rpt - 1) / (16 * c->rs_rpt));
+            b += j.blocks_x * (uint32_t)((j.ch + 16 * rpt - 1) / (16 * rpt));
         }
         c->gen_blocks[g] = b;
         if (c->h_gens[g].empty()) continue;
@@ -407,7 +415,7 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
         refs.reserve(b);
         for (size_t ji = 0; ji < c->h_gens[g].size(); ji++) {
             const HtResampleJob &j = c->h_gens[g][ji];
-            const uint32_t nby = (uint32_t)((j.ch + 16 * c->rs_rpt - 1) / (16 * c->rs_rpt));
+            const uint32_t nby = (uint32_t)((j.ch + 16 * rpt - 1) / (16 * rpt));
             for (uint32_t y = 0; y < nby; y++)
                 for (uint32_t x = 0; x < j.blocks_x; x++) refs.push_back(HtBlockRef{(uint16_t)ji, (uint16_t)x, (uint16_t)y, 0});
         }

@@ -182,6 +182,7 @@ struct ht_ctx {
     std::vector<HtBlockRef *> d_gen_blocks;  // per generation: block -> (job, bx, by)
     HtBlockRef *d_tile_refs = nullptr;        // per-frame tile -> (scale, tx, ty)
     std::vector<uint32_t> gen_blocks;
+    std::vector<int> gen_rpt;  // k_resample rows per thread chosen per generation (tile = 64 x 16*rpt): big tiles for big levels
     std::vector<HtScanScale> h_scales;
     HtScanScale *d_scales = nullptr;
     uint32_t tiles_per_frame = 0;

@@ -139,8 +139,11 @@ __device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap (&cx)
     return o;
 }
 
+#ifndef HT_RS_WPS
+#define HT_RS_WPS 1
+#endif
 template <int RPT>
-__global__ __launch_bounds__(256) void k_resample(const HtResampleJob *__restrict__ jobs, const HtBlockRef *__restrict__ refs,
+__global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob *__restrict__ jobs, const HtBlockRef *__restrict__ refs,
                                                   uint8_t *__restrict__ arena, uint64_t arena_stride, uint32_t blocks_per_frame,
                                                   uint32_t nframes) {
     constexpr int TH = 16 * RPT;               // destination rows per tile
@@ -276,10 +279,10 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         if (c->gen_blocks[g] == 0) continue;
         HtProfScope ps(c, "resample");
         const dim3 rgrid((c->gen_blocks[g] * (uint32_t)c->nframes + 7u) & ~7u);
-        if (c->rs_rpt == 4)
+        if (c->gen_rpt[g] == 4)
             hipLaunchKernelGGL(k_resample<4>, rgrid, dim3(256), 0, c->stream, c->d_gens[g], c->d_gen_blocks[g], c->d_arena,
                                c->arena_stride, c->gen_blocks[g], (uint32_t)c->nframes);
-        else if (c->rs_rpt == 2)
+        else if (c->gen_rpt[g] == 2)
             hipLaunchKernelGGL(k_resample<2>, rgrid, dim3(256), 0, c->stream, c->d_gens[g], c->d_gen_blocks[g], c->d_arena,
                                c->arena_stride, c->gen_blocks[g], (uint32_t)c->nframes);
         else

@@ -1251,7 +1251,7 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
                 HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_deep_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 attr_set = true;
             }
-            hipLaunchKernelGGL(k_scan_deep_lds, dim3(256), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
+            hipLaunchKernelGGL(k_scan_deep_lds, dim3(getenv("HT_DEBUG_DEEP_GRID") ? atoi(getenv("HT_DEBUG_DEEP_GRID")) : 256), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                                c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, c->d_queue, c->queue_capacity,
                                c->d_hits, c->hit_capacity, c->d_counters, stats);
         } else if (dv && atoi(dv) == 3)

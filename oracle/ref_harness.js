@@ -104,6 +104,14 @@ function runCamshift(cs, base) {
       out.calls.push({ frame: i, sw: [sw.x, sw.y, sw.width, sw.height], x: to.x, y: to.y, width: to.width, height: to.height, angle: to.angle });
     }
   }
+  /* debug getters (camshift.js:172-196): the back-projection of the last tracked frame */
+  const bp = tr.getBackProjectionImg();
+  out.backprojection_crc = crc32All(bp.data);
+  const pdf = tr.getPdf();
+  out.pdf_samples = [[0, 0], [cs.w >> 1, cs.h >> 1], [cs.w - 1, cs.h - 1], [cs.rect[0] + 3, cs.rect[1] + 3]].map(function (p) {
+    const x = Math.min(Math.max(p[0], 0), cs.w - 1), y = Math.min(Math.max(p[1], 0), cs.h - 1);
+    return [x, y, pdf[x][y]];
+  });
   return out;
 }
 

@@ -60,6 +60,12 @@ job.camshift.forEach(function (cs) {
     if (call.angle === null) check(Number.isNaN(to.angle), cs.name + ' call ' + i + ': NaN angle');
     else { let d = Math.abs(to.angle - call.angle); d = Math.min(d, Math.abs(d - Math.PI)); check(d <= 0.5 * Math.PI / 180, cs.name + ' call ' + i + ': angle'); }
   });
+  if (g.backprojection_crc !== undefined) { /* debug getters, rebuilt on the host on demand */
+    const bp = tracker.getBackProjectionImg();
+    check(crc32(bp.data) === g.backprojection_crc, cs.name + ': getBackProjectionImg bytes');
+    const pdf = tracker.getPdf();
+    g.pdf_samples.forEach(function (p) { check(pdf[p[0]][p[1]] === p[2], cs.name + ': getPdf[' + p[0] + '][' + p[1] + ']'); });
+  }
   tracker.release();
 });
 

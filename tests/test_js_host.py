@@ -54,7 +54,7 @@ def test_js_host_parity_on_gpu(tmp_path):
                                   frame=ffile(c["gen"], c["w"], c["h"]), golden={k: c[k] for k in ("whitebalance", "gray_rgba_crc", "raw", "grouped", "min_neighbors")}))
     for c in cam["cases"]:
         job["camshift"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=[ffile(g, c["w"], c["h"]) for g in c["gen"]],
-                                    golden={k: c[k] for k in ("rect", "calcAngles", "calls")}))
+                                    golden={k: c[k] for k in ("rect", "calcAngles", "calls", "backprojection_crc", "pdf_samples")}))
     for c in ft["cases"]:
         job["facetrackr"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=[ffile(g, c["w"], c["h"]) for g in c["gen"]],
                                       golden={k: c[k] for k in ("params", "calls", "events")}))

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                                                    const HtDevLevel *__restrict__ levels, const HtScanScale *__restrict__ scales,
                                                    const HtBlockRef *__restrict__ tile_refs, const HtTileFeature *__restrict__ feats,
                                                    const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,
-                                                   int stop_stage, uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
+                                                   int stop_stage, int force_exact, uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
                                                    uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
                                                    HtCounters *__restrict__ ctr, unsigned long long *__restrict__ stats) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TILE_BYTES];
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 bool pass = valid[u] && Fv[u] >= HT_GEN_FMIN[0];
-                if (valid[u] && Fv[u] == HT_GEN_FTIE[0])  // exact tie: the sequential binary64 sum decides
+                if (valid[u] && (Fv[u] == HT_GEN_FTIE[0] || force_exact))  // exact tie: the sequential binary64 sum decides
                     pass = !(eval_stage_lds(lds, 2u * (yy[u] * PITCH0 + xx[u]), feats + st0.first, st0.count) < st0.threshold);
                 const unsigned long long m = __ballot(pass);
                 if (m) {
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             if (wv == 0) {
                 const uint32_t Fv = s_F[lane];
                 bool pass = valid && Fv >= HT_GEN_FMIN[s];
-                if (valid && Fv == HT_GEN_FTIE[s])  // exact tie with the threshold: let the sequential binary64 sum decide
+                if (valid && (Fv == HT_GEN_FTIE[s] || force_exact))  // exact tie with the threshold: let the sequential binary64 sum decide
                     pass = !(eval_stage_lds(lds, B, F, st.count) < st.threshold);
                 const unsigned long long m = __ballot(pass);
                 const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 // generated straight-line stage: exact integer decision (see tools/gen_cascade_code.py)
                 const uint32_t Fv = ht_gen_stage(s, lds + (valid ? B : 0u));
                 pass = valid && Fv >= HT_GEN_FMIN[s];
-                if (valid && Fv == HT_GEN_FTIE[s])  // exact tie with the threshold: let the sequential binary64 sum decide
+                if (valid && (Fv == HT_GEN_FTIE[s] || force_exact))  // exact tie with the threshold: let the sequential binary64 sum decide
                     pass = !(eval_stage_lds(lds, B, F, st.count) < st.threshold);
             } else {
                 sum = eval_stage_lds(lds, valid ? B : 0u, F, st.count);
@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__
                         alive = false;
                         break;
                     }
-                    need_exact = (Ssum == st.thri) || (j == nstages - 1);
+                    need_exact = (Ssum == st.thri) || (j == nstages - 1) || use_int == 2;
                 }
                 if (need_exact) {
                     const double sum = patch_stage_sum_exact(patch, feats + st.first, st.count, st.maxpts, lane);
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
                                                                    const HtDevLevel *__restrict__ levels, int next,
                                                                    const HtPackedFeature *__restrict__ packed, uint32_t packed_count,
                                                                    uint32_t packed_first, const HtDevStage *__restrict__ stages, int nstages,
-                                                                   const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
+                                                                   int force_exact, const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
                                                                    ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr,
                                                                    unsigned long long *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
                 alive = false;
                 break;
             }
-            if (Ssum == st.thri || j == nstages - 1) {
+            if (Ssum == st.thri || j == nstages - 1 || force_exact) {
                 // sequential binary64 sum in the reference's order (ccv.js:186-221): fire bits by ballot, adds in feature order
                 double sum = 0.0;
                 for (uint32_t kb = 0; kb < st.count; kb += 64) {
@@ -1227,16 +1227,18 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     // measurement knobs (never set in production): stop the tile kernel before a stage / tune the hand-off rule
     const char *dbg_stop = getenv("HT_DEBUG_STOP_STAGE"), *dbg_bias = getenv("HT_DEBUG_DEEP_BIAS");
     const int stop_stage = dbg_stop ? atoi(dbg_stop) : -1;
+    // test knob: treat every integer stage decision as an exact tie, i.e. always take the sequential-binary64 fallback
+    const int force_exact = getenv("HT_DEBUG_FORCE_EXACT") ? atoi(getenv("HT_DEBUG_FORCE_EXACT")) : 0;
     if (dbg_bias) c->deep_bias = (uint32_t)atoi(dbg_bias);
     {
         HtProfScope ps(c, "scan_tiles");
         if (gen)
             hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                               c->d_scales, c->d_tile_refs, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, c->tiles_per_frame,
+                               c->d_scales, c->d_tile_refs, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, c->tiles_per_frame,
                                total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
         else
             hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                               c->d_scales, c->d_tile_refs, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, c->tiles_per_frame,
+                               c->d_scales, c->d_tile_refs, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, c->tiles_per_frame,
                                total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
         HT_HIP(c, hipGetLastError());
     }
@@ -1252,7 +1254,7 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
                 attr_set = true;
             }
             hipLaunchKernelGGL(k_scan_deep_lds, dim3(getenv("HT_DEBUG_DEEP_GRID") ? atoi(getenv("HT_DEBUG_DEEP_GRID")) : 256), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
-                               c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, c->d_queue, c->queue_capacity,
+                               c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, force_exact, c->d_queue, c->queue_capacity,
                                c->d_hits, c->hit_capacity, c->d_counters, stats);
         } else if (dv && atoi(dv) == 3)
             hipLaunchKernelGGL(k_scan_deep_wg, dim3(4096), dim3(256), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
@@ -1264,7 +1266,7 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
                                c->hit_capacity, c->d_counters, stats);
         else
         hipLaunchKernelGGL(k_scan_deep, dim3(2048), dim3(64 * DEEP_WAVES), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
-                           c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
+                           c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? (force_exact ? 2 : 1) : 0, c->d_queue, c->queue_capacity, c->d_hits,
                            c->hit_capacity, c->d_counters, stats);
         HT_HIP(c, hipGetLastError());
     }

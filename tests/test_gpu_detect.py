@@ -189,3 +189,18 @@ def test_best_faces_matches_per_frame_grouping(ctx):
         else:
             b = per[f][int(np.argmax(per[f]["confidence"]))]
             assert best[f].tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("deep_v", ["4", "2"])
+def test_exact_tie_fallback_path(ctx, cascade, deep_v, monkeypatch):
+    """The integer stage decisions fall back to the sequential binary64 sum on an exact tie with the threshold — a case the
+    built-in cascade practically never produces.  HT_DEBUG_FORCE_EXACT makes every decision take that fallback (tile kernel
+    incl. its sparse phase, and both deep kernels): results must be unchanged."""
+    frames = synth.mixed_batch(6, 320, 240, seed0=1234)
+    want, _ = ctx.detect_raw(frames)
+    monkeypatch.setenv("HT_DEBUG_FORCE_EXACT", "1")
+    monkeypatch.setenv("HT_DEBUG_DEEP_V", deep_v)
+    got, _ = ctx.detect_raw(frames)
+    assert len(want) > 20 and got.tobytes() == want.tobytes()
+    ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(6)])
+    assert_hits_equal(got, ref)

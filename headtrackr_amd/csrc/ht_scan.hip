@@ -877,6 +877,28 @@ __device__ __forceinline__ bool packed_fire(const uint8_t *patch, const uint4 A,
     return pmin > nmax;
 }
 
+// wave64 integer sum with DPP row shifts / row broadcasts (VALU-only, ~10 instructions) instead of a ds_bpermute shuffle tree
+// (6 dependent LDS round trips): the critical path of a window through the deep stages is what the deep kernel costs.
+// Canonical gfx9 sequence: row_shr 1,2,3 on the input, row_shr 4 / 8 with bank masks, row_bcast 15 / 31; total in lane 63.
+__device__ __forceinline__ int wave_sum_i32_dpp(int v) {
+    int s = v + __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    s += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);         // row_shr:2
+    s += __builtin_amdgcn_update_dpp(0, v, 0x113, 0xf, 0xf, true);         // row_shr:3
+    s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xe, true);         // row_shr:4, banks 1-3
+    s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xc, true);         // row_shr:8, banks 2-3
+    s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, true);         // row_bcast:15 into rows 1, 3
+    s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, true);         // row_bcast:31 into rows 2, 3
+    return __builtin_amdgcn_readlane(s, 63);
+}
+// 64-bit sum of per-lane values in (-2^40, 2^40): three 21-bit limbs of (v + 2^40), each limb sum < 2^27
+__device__ __forceinline__ long long wave_sum_i64_dpp(long long v) {
+    const unsigned long long u = (unsigned long long)(v + (1ll << 40));
+    const long long l0 = wave_sum_i32_dpp((int)(u & 0x1fffffu));
+    const long long l1 = wave_sum_i32_dpp((int)((u >> 21) & 0x1fffffu));
+    const long long l2 = wave_sum_i32_dpp((int)(u >> 42));
+    return l0 + (l1 << 21) + (l2 << 42) - (64ll << 40);
+}
+
 __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                                    const HtDevLevel *__restrict__ levels, int next,
                                                                    const HtPackedFeature *__restrict__ packed, uint32_t packed_count,
@@ -885,14 +907,19 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
                                                                    ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr,
                                                                    unsigned long long *__restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
-    uint4 *tab = reinterpret_cast<uint4 *>(dyn_lds);                       // packed_count x 32 B
-    uint8_t *patches = dyn_lds + (size_t)packed_count * sizeof(HtPackedFeature);  // DEEPL_WAVES x PATCH_BYTES
+    // LDS: [packed feature table][stage table][per wave: window patch (768 B) + 64 selected alphas (512 B)]
+    uint4 *tab = reinterpret_cast<uint4 *>(dyn_lds);
+    HtDevStage *s_stages = reinterpret_cast<HtDevStage *>(dyn_lds + (size_t)packed_count * sizeof(HtPackedFeature));
+    uint8_t *per_wave = reinterpret_cast<uint8_t *>(s_stages + 64);
     const uint32_t n = min(ctr->nqueue, queue_cap);
     if (blockIdx.x * DEEPL_WAVES >= n) return;  // nothing for this workgroup: skip the table copy
     for (uint32_t i = threadIdx.x; i < packed_count * 2u; i += blockDim.x) tab[i] = reinterpret_cast<const uint4 *>(packed)[i];
+    for (uint32_t i = threadIdx.x; i < (uint32_t)nstages * (sizeof(HtDevStage) / 16); i += blockDim.x)
+        reinterpret_cast<uint4 *>(s_stages)[i] = reinterpret_cast<const uint4 *>(stages)[i];
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint8_t *patch = patches + wv * PATCH_BYTES;
+    uint8_t *patch = per_wave + wv * (PATCH_BYTES + 512);
+    double *sel_buf = reinterpret_cast<double *>(patch + PATCH_BYTES);
     const uint32_t wave = blockIdx.x * DEEPL_WAVES + wv, nwaves = gridDim.x * DEEPL_WAVES;
     unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
     for (uint32_t e = wave; e < n; e += nwaves) {
@@ -934,7 +961,7 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
         bool alive = true;
         double conf = 0.0;
         for (int j = (int)ent.pad; j < nstages; j++) {
-            const HtDevStage st = stages[j];
+            const HtDevStage st = s_stages[j];
             const uint32_t base = st.first - packed_first;  // index of the stage's first record in the LDS table
             if (lane == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
             long long acc = 0;
@@ -942,13 +969,15 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
                 const uint4 A = tab[(base + k) * 2u], Bq = tab[(base + k) * 2u + 1u];
                 acc += packed_fire(patch, A, Bq.x) ? (long long)(int32_t)Bq.z : (long long)(int32_t)Bq.y;
             }
-            const long long Ssum = wave_sum_i64(acc);
+            const long long Ssum = wave_sum_i64_dpp(acc);
             if (Ssum < st.thri) {  // sum < threshold decided exactly, independent of summation order
                 alive = false;
                 break;
             }
             if (Ssum == st.thri || j == nstages - 1 || force_exact) {
-                // sequential binary64 sum in the reference's order (ccv.js:186-221): fire bits by ballot, adds in feature order
+                // sequential binary64 sum in the reference's order (ccv.js:186-221): every lane parks the alpha its feature
+                // selected in LDS, then the wave adds them in feature order from broadcast reads (the loads do not depend
+                // on the running sum, so only the adds form the chain)
                 double sum = 0.0;
                 for (uint32_t kb = 0; kb < st.count; kb += 64) {
                     const uint32_t k = kb + lane;
@@ -958,7 +987,18 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
                         const int32_t ai = packed_fire(patch, A, Bq.x) ? (int32_t)Bq.z : (int32_t)Bq.y;
                         sel = (double)ai / 1e8;  // == alpha exactly (checked when the table was packed)
                     }
-                    sum = seq_add_lanes(sum, sel, min(64u, st.count - kb));
+                    sel_buf[lane] = sel;  // lanes >= nn park 0.0: adding +0.0 never changes a binary64 sum that is not -0.0
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t nn = min(64u, st.count - kb);
+                    uint32_t t = 0;
+                    for (; t + 8 <= nn; t += 8) {
+                        const double v0 = sel_buf[t], v1 = sel_buf[t + 1], v2 = sel_buf[t + 2], v3 = sel_buf[t + 3];
+                        const double v4 = sel_buf[t + 4], v5 = sel_buf[t + 5], v6 = sel_buf[t + 6], v7 = sel_buf[t + 7];
+                        sum = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(sum, v0), v1), v2), v3), v4), v5), v6), v7);
+                    }
+                    for (; t < nn; t++) sum = __dadd_rn(sum, sel_buf[t]);
+                    __builtin_amdgcn_wave_barrier();
                 }
                 if (sum < st.threshold) {  // ccv.js:222
                     alive = false;
@@ -1247,7 +1287,7 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
         const char *dv = getenv("HT_DEBUG_DEEP_V");
         const int deep_v = dv ? atoi(dv) : 4;
         if (deep_v == 4 && c->packed_count && c->h_stages[split].first >= c->packed_first) {
-            const size_t lds = (size_t)c->packed_count * sizeof(HtPackedFeature) + (size_t)DEEPL_WAVES * PATCH_BYTES;
+            const size_t lds = (size_t)c->packed_count * sizeof(HtPackedFeature) + 64 * sizeof(HtDevStage) + (size_t)DEEPL_WAVES * (PATCH_BYTES + 512);
             static bool attr_set = false;
             if (!attr_set) {
                 HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_deep_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));

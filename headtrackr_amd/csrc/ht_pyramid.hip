@@ -172,21 +172,31 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         const bool in_lds = (sw4 * 4 <= RS_SP) && (sh <= SR);
         const int npx = min(4, J.dw - x0);
         if (in_lds) {
-            // source rows as aligned dwords, fixed 40-dword pitch so the index split is a constant division; all loads
-            // are issued before the first LDS write
-            constexpr int RW = RS_SP / 4, KL = (SR * RW + 255) / 256;
-            const uint8_t *sbase = src + (size_t)ya * J.src_stride + xa;
-            uint32_t v[KL];
+            // source rows as aligned dwords, all loads issued before the first LDS write.  8 threads share a row (5
+            // consecutive dwords each = the 160-byte LDS pitch), 32 rows per pass: the index arithmetic is one add per
+            // pass instead of a division per dword (the staging loop used to be as long as the pixel arithmetic itself).
+            constexpr int KR = (SR + 31) / 32;
+            const int r0 = tid >> 3, cg = (tid & 7) * 5;
+            const uint8_t *sbase = src + (size_t)ya * J.src_stride + xa + 4 * cg;
+            uint32_t v[KR][5];
 #pragma unroll
-            for (int k = 0; k < KL; k++) {
-                const int i = tid + k * 256, r = i / RW, c = i - r * RW;
-                v[k] = 0;
-                if (r < sh && c < sw4) v[k] = *reinterpret_cast<const uint32_t *>(sbase + (size_t)r * J.src_stride + 4 * c);
+            for (int k = 0; k < KR; k++) {
+                const int r = r0 + 32 * k;
+                const uint32_t *rowp = reinterpret_cast<const uint32_t *>(sbase + (size_t)r * J.src_stride);
+#pragma unroll
+                for (int j = 0; j < 5; j++) {
+                    v[k][j] = 0;
+                    if (r < sh && cg + j < sw4) v[k][j] = rowp[j];
+                }
             }
 #pragma unroll
-            for (int k = 0; k < KL; k++) {
-                const int i = tid + k * 256;
-                if (i < SR * RW) *reinterpret_cast<uint32_t *>(&s_src[i * 4]) = v[k];
+            for (int k = 0; k < KR; k++) {
+                const int r = r0 + 32 * k;
+                if (r < SR) {
+                    uint32_t *dstp = reinterpret_cast<uint32_t *>(&s_src[r * RS_SP + 4 * cg]);
+#pragma unroll
+                    for (int j = 0; j < 5; j++) dstp[j] = v[k][j];
+                }
             }
             __syncthreads();
             RsTap cx[4];

@@ -491,85 +491,6 @@ __device__ __forceinline__ double patch_stage_sum_exact(const uint8_t *patch, co
     return sum;
 }
 
-// v1: straightforward per-stage loop (46 VGPRs, 8 waves/SIMD); kept for A/B against the prefetching version below
-__global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep_v1(const uint8_t *__restrict__ arena, uint64_t arena_stride,
-                                                               const HtDevLevel *__restrict__ levels, int next,
-                                                               const HtPatchFeature *__restrict__ feats,
-                                                               const HtDevStage *__restrict__ stages, int nstages, int use_int,
-                                                               const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
-                                                               ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr,
-                                                               unsigned long long *__restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_patch[DEEP_WAVES][PATCH_BYTES];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    uint8_t *patch = s_patch[wv];
-    const uint32_t wave = blockIdx.x * DEEP_WAVES + wv, nwaves = gridDim.x * DEEP_WAVES;
-    unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
-    const uint32_t n = min(ctr->nqueue, queue_cap);
-    for (uint32_t e = wave; e < n; e += nwaves) {
-        const HtQueueEntry ent = queue[e];
-        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
-                     (uint32_t)ent.y)
-        // load the patch (wave-private: no workgroup barrier needed, LDS ops of one wave complete in order)
-        for (uint32_t i = lane; i < 288; i += 64) {  // plane 0: 24 rows x 12 u16 (window origin is 2-byte aligned)
-            const uint32_t r = i / 12, c2 = (i - r * 12) * 2;
-            *reinterpret_cast<uint16_t *>(&patch[r * 24 + c2]) = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);
-        }
-        for (uint32_t i = lane; i < 144; i += 64) {  // plane 1: 12 x 12 bytes
-            const uint32_t r = i / 12, c = i - r * 12;
-            patch[PATCH1 + i] = fb[o1 + r * (uint32_t)s1 + c];
-        }
-        if (lane < 36) {  // plane 2: 6 x 6 bytes
-            const uint32_t r = lane / 6, c = lane - r * 6;
-            patch[PATCH2 + lane] = fb[o2 + r * (uint32_t)s2 + c];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        bool alive = true;
-        double conf = 0.0;
-        for (int j = (int)ent.pad; j < nstages; j++) {
-            const HtDevStage st = stages[j];
-            const HtPatchFeature *F = feats + st.first;
-            if (lane == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
-            bool need_exact = true;
-            if (use_int) {
-                long long acc = 0;
-                for (uint32_t k = lane; k < st.count; k += 64) acc += patch_fire(patch, &F[k], st.maxpts) ? F[k].a1i : F[k].a0i;
-                const long long Ssum = wave_sum_i64(acc);
-                if (Ssum < st.thri) {  // sum < threshold decided exactly, independent of summation order
-                    alive = false;
-                    break;
-                }
-                need_exact = (Ssum == st.thri) || (j == nstages - 1);
-            }
-            if (need_exact) {
-                const double sum = patch_stage_sum_exact(patch, F, st.count, st.maxpts, lane);
-                if (sum < st.threshold) {  // ccv.js:222
-                    alive = false;
-                    break;
-                }
-                conf = sum;
-            }
-        }
-        if (alive && lane == 0) {
-            if (my_stats) atomicAdd(&my_stats[nstages], 1ull);
-            const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
-            if (pos < hit_cap) {
-                ht_hit h;
-                h.frame = ent.frame;
-                h.x = ent.x;
-                h.y = ent.y;
-                h.scale = ent.scale;
-                h.q = ent.q;
-                h.reserved0 = 0;
-                h.reserved1 = 0;
-                h.sum = conf;
-                hits[pos] = h;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // the next window overwrites the patch
-    }
-}
-
 // registers holding one lane's feature record (loaded one chunk ahead of its use)
 struct PatchFeatRegs {
     uint4 P, N;        // 8 + 8 u16 offsets
@@ -717,146 +638,6 @@ __global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__
             }
         }
         __builtin_amdgcn_wave_barrier();  // the next window overwrites the patch
-    }
-}
-
-// ---- deep kernel, workgroup form ---------------------------------------------------------------------------------------
-// One WORKGROUP (4 wavefronts) per surviving window.  k_scan_deep's run time is the critical path of a single face window
-// (33 sequential 64-feature chunks from stage 8 to 15, each waiting on L2 for its feature records) no matter how few
-// windows there are; here a stage's features are spread over 256 lanes, so stage 15 is 3 steps instead of 9 and the whole
-// chain ~12 steps instead of 33.  Partial integer sums meet in LDS (exact, order-free); the sequential binary64 pass of
-// the last stage / of an exact tie uses the 4 waves' ballot masks.
-__global__ __launch_bounds__(256) void k_scan_deep_wg(const uint8_t *__restrict__ arena, uint64_t arena_stride,
-                                                      const HtDevLevel *__restrict__ levels, int next,
-                                                      const HtPatchFeature *__restrict__ feats, const HtDevStage *__restrict__ stages,
-                                                      int nstages, int use_int, const HtQueueEntry *__restrict__ queue, uint32_t queue_cap,
-                                                      ht_hit *__restrict__ hits, uint32_t hit_cap, HtCounters *__restrict__ ctr,
-                                                      unsigned long long *__restrict__ stats) {
-    __shared__ __attribute__((aligned(16))) uint8_t patch[PATCH_BYTES];
-    __shared__ long long s_part[4];
-    __shared__ unsigned long long s_mask[16 * 4];  // fire bits of up to 16 x 256 features
-    __shared__ double s_sum;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
-    unsigned long long *my_stats = stats ? stats + (size_t)(blockIdx.x & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
-    const uint32_t n = min(ctr->nqueue, queue_cap);
-    for (uint32_t e = blockIdx.x; e < n; e += gridDim.x) {
-        const HtQueueEntry ent = queue[e];
-        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
-                     (uint32_t)ent.y)
-        int j = (int)ent.pad;
-        HtDevStage st = stages[j];
-        PatchFeatRegs cur;
-        if (tid < st.count) cur = load_feat(feats + st.first + tid);
-        {   // window patch: 288 halfwords of plane 0, 144 bytes of plane 1, 36 bytes of plane 2 (all issued together)
-            uint32_t pa0 = 0, pa1 = 0, pb = 0, pc = 0;
-            {
-                const uint32_t r = tid / 12u, c2 = (tid - r * 12u) * 2u;
-                pa0 = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);  // tid < 256 <= 288
-            }
-            if (tid < 32u) {
-                const uint32_t i = tid + 256u, r = i / 12u, c2 = (i - r * 12u) * 2u;
-                pa1 = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);
-            }
-            if (tid >= 64u && tid < 208u) {
-                const uint32_t i = tid - 64u, r = i / 12u, c = i - r * 12u;
-                pb = fb[o1 + r * (uint32_t)s1 + c];
-            }
-            if (tid >= 208u && tid < 244u) {
-                const uint32_t i = tid - 208u, r = i / 6u, c = i - r * 6u;
-                pc = fb[o2 + r * (uint32_t)s2 + c];
-            }
-            __syncthreads();  // the previous window's readers are done with the patch
-            *reinterpret_cast<uint16_t *>(&patch[2u * tid]) = (uint16_t)pa0;
-            if (tid < 32u) *reinterpret_cast<uint16_t *>(&patch[2u * (tid + 256u)]) = (uint16_t)pa1;
-            if (tid >= 64u && tid < 208u) patch[PATCH1 + tid - 64u] = (uint8_t)pb;
-            if (tid >= 208u && tid < 244u) patch[PATCH2 + tid - 208u] = (uint8_t)pc;
-        }
-        __syncthreads();
-        bool alive = true;
-        double conf = 0.0;
-        uint32_t kb = 0;
-        long long acc = 0;
-        while (true) {
-            const bool stage_ends = kb + 256u >= st.count;
-            int jn = j;
-            uint32_t kbn = kb + 256u;
-            HtDevStage stn = st;
-            if (stage_ends) {
-                jn = j + 1;
-                kbn = 0;
-                if (jn < nstages) stn = stages[jn];
-            }
-            PatchFeatRegs nxt = cur;
-            if (jn < nstages && kbn + tid < stn.count) nxt = load_feat(feats + stn.first + kbn + tid);  // one chunk ahead
-            if (kb == 0 && tid == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
-            if (use_int && kb + tid < st.count) acc += fire_regs(patch, cur, st.maxpts) ? cur.a1i : cur.a0i;
-            if (stage_ends) {
-                bool need_exact = true;
-                if (use_int) {
-                    const long long w = wave_sum_i64(acc);
-                    acc = 0;
-                    if (lane == 0) s_part[wv] = w;
-                    __syncthreads();
-                    const long long Ssum = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-                    __syncthreads();
-                    if (Ssum < st.thri) {  // exact, order-free
-                        alive = false;
-                        break;
-                    }
-                    need_exact = (Ssum == st.thri) || (j == nstages - 1);
-                }
-                if (need_exact) {  // sequential binary64 sum in the reference's order (ccv.js:186-221)
-                    const HtPatchFeature *F = feats + st.first;
-                    const uint32_t nch = (st.count + 255u) >> 8;
-                    for (uint32_t c = 0; c < nch && c < 16u; c++) {
-                        const uint32_t k = c * 256u + tid;
-                        bool fire = false;
-                        if (k < st.count) fire = patch_fire(patch, &F[k], st.maxpts);
-                        const unsigned long long mm = __ballot(fire);
-                        if (lane == 0) s_mask[c * 4 + wv] = mm;
-                    }
-                    __syncthreads();
-                    if (wv == 0) {
-                        double sum = 0.0;
-                        for (uint32_t k = 0; k < st.count; k++) {
-                            const uint4 A = *reinterpret_cast<const uint4 *>(&F[k].a0);  // uniform: {a0, a1}
-                            const bool f1 = (s_mask[k >> 6] >> (k & 63u)) & 1ull;
-                            sum = __dadd_rn(sum, __hiloint2double((int)(f1 ? A.w : A.y), (int)(f1 ? A.z : A.x)));
-                        }
-                        if (lane == 0) s_sum = sum;
-                    }
-                    __syncthreads();
-                    const double sum = s_sum;
-                    __syncthreads();
-                    if (sum < st.threshold) {  // ccv.js:222
-                        alive = false;
-                        break;
-                    }
-                    conf = sum;
-                }
-                if (jn >= nstages) break;
-            }
-            j = jn;
-            kb = kbn;
-            st = stn;
-            cur = nxt;
-        }
-        if (alive && tid == 0) {
-            if (my_stats) atomicAdd(&my_stats[nstages], 1ull);
-            const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
-            if (pos < hit_cap) {
-                ht_hit h;
-                h.frame = ent.frame;
-                h.x = ent.x;
-                h.y = ent.y;
-                h.scale = ent.scale;
-                h.q = ent.q;
-                h.reserved0 = 0;
-                h.reserved1 = 0;
-                h.sum = conf;
-                hits[pos] = h;
-            }
-        }
     }
 }
 
@@ -1299,15 +1080,7 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
             hipLaunchKernelGGL(k_scan_deep_lds, dim3(getenv("HT_DEBUG_DEEP_GRID") ? atoi(getenv("HT_DEBUG_DEEP_GRID")) : 512), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                                c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, force_exact, c->d_queue, c->queue_capacity,
                                c->d_hits, c->hit_capacity, c->d_counters, stats);
-        } else if (dv && atoi(dv) == 3)
-            hipLaunchKernelGGL(k_scan_deep_wg, dim3(4096), dim3(256), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
-                               c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
-                               c->hit_capacity, c->d_counters, stats);
-        else if (dv && atoi(dv) == 1)
-            hipLaunchKernelGGL(k_scan_deep_v1, dim3(2048), dim3(64 * DEEP_WAVES), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
-                               c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? 1 : 0, c->d_queue, c->queue_capacity, c->d_hits,
-                               c->hit_capacity, c->d_counters, stats);
-        else
+        } else
         hipLaunchKernelGGL(k_scan_deep, dim3(2048), dim3(64 * DEEP_WAVES), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                            c->d_patch_feats, c->d_stages, (int)c->nstages, c->decimal_alphas ? (force_exact ? 2 : 1) : 0, c->d_queue, c->queue_capacity, c->d_hits,
                            c->hit_capacity, c->d_counters, stats);

@@ -215,7 +215,7 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     }
     if (const char *e = getenv("HT_DEBUG_RS_RPT")) {  // measurement knob
         const int v = atoi(e);
-        if (v == 1 || v == 2 || v == 4) c->rs_rpt = v;
+        if (v >= 1 && v <= HT_RS_MAX_PASSES) c->rs_rpt = v;
     }
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
@@ -238,16 +238,12 @@ static void free_geometry(ht_ctx *c) {
     if (c->d_arena) (void)hipFree(c->d_arena), c->d_arena = nullptr;
     if (c->d_scales) (void)hipFree(c->d_scales), c->d_scales = nullptr;
     if (c->d_queue) (void)hipFree(c->d_queue), c->d_queue = nullptr;
-    for (auto p : c->d_gens)
-        if (p) (void)hipFree(p);
     for (auto p : c->d_gen_blocks)
         if (p) (void)hipFree(p);
     c->d_gen_blocks.clear();
     if (c->d_tile_refs) (void)hipFree(c->d_tile_refs), c->d_tile_refs = nullptr;
-    c->d_gens.clear();
     c->h_gens.clear();
     c->gen_blocks.clear();
-    c->gen_rpt.clear();
     c->h_scales.clear();
 }
 
@@ -392,37 +388,33 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
             }
         }
     }
-    c->d_gens.assign(ngen, nullptr);
     c->d_gen_blocks.assign(ngen, nullptr);
     c->gen_blocks.assign(ngen, 0);
-    c->gen_rpt.assign(ngen, c->rs_rpt);
     for (int g = 1; g < ngen; g++) {
-        // tile height per generation: 64 x 64 destination pixels for the big levels, smaller tiles where the levels are
-        // small (a 40 x 30 level fills 29 % of a 64 x 64 tile but 59 % of a 64 x 32 one)
-        int maxh = 0;
-        for (auto &j : c->h_gens[g]) maxh = std::max(maxh, j.ch);
-        if (!getenv("HT_DEBUG_RS_RPT")) c->gen_rpt[g] = maxh >= 160 ? 4 : (maxh >= 48 ? 2 : 1);
-        const int rpt = c->gen_rpt[g];
-        uint32_t b = 0;
+        // k_resample tile records: 64 columns x np passes of 16 rows.  np is bounded by the LDS source window (the rows
+        // a tile touches: ~16 np ry + 3 <= HT_RS_SRC_ROWS; the kernel falls back to HBM taps if a tile still does not fit)
+        // and by rs_rpt; a canvas of P = ceil(ch / 16) passes is then cut into ceil(P / np) tiles of near-equal pass counts.
+        std::vector<HtResampleJob> tiles;
         for (auto &j : c->h_gens[g]) {
-            j.block_begin = b;
-            j.blocks_x = (uint32_t)((j.cw + 63) / 64);   // k_resample tile: 64 x (16 * rs_rpt) destination pixels
-            b += j.blocks_x * (uint32_t)((j.ch + 16 * rpt - 1) / (16 * rpt));
+            int npmax = 1;
+            for (int t = 2; t <= std::min(c->rs_rpt, HT_RS_MAX_PASSES); t++)
+                if ((int)std::ceil(16.0 * t * j.ry) + 3 <= HT_RS_SRC_ROWS) npmax = t;
+            const int passes = (j.ch + 15) / 16, nby = (passes + npmax - 1) / npmax, nbx = (j.cw + 63) / 64;
+            int pass0 = 0;
+            for (int y = 0; y < nby; y++) {
+                const int np = passes / nby + (y < passes % nby ? 1 : 0);
+                for (int x = 0; x < nbx; x++) {
+                    HtResampleJob t = j;
+                    t.bx = (uint16_t)x, t.pass0 = (uint16_t)pass0, t.np = (uint16_t)np, t.pad = 0;
+                    tiles.push_back(t);
+                }
+                pass0 += np;
+            }
         }
-        c->gen_blocks[g] = b;
-        if (c->h_gens[g].empty()) continue;
-        std::vector<HtBlockRef> refs;
-        refs.reserve(b);
-        for (size_t ji = 0; ji < c->h_gens[g].size(); ji++) {
-            const HtResampleJob &j = c->h_gens[g][ji];
-            const uint32_t nby = (uint32_t)((j.ch + 16 * rpt - 1) / (16 * rpt));
-            for (uint32_t y = 0; y < nby; y++)
-                for (uint32_t x = 0; x < j.blocks_x; x++) refs.push_back(HtBlockRef{(uint16_t)ji, (uint16_t)x, (uint16_t)y, 0});
-        }
-        HT_HIP(c, hipMalloc(&c->d_gen_blocks[g], refs.size() * sizeof(HtBlockRef)));
-        HT_HIP(c, hipMemcpy(c->d_gen_blocks[g], refs.data(), refs.size() * sizeof(HtBlockRef), hipMemcpyHostToDevice));
-        HT_HIP(c, hipMalloc(&c->d_gens[g], c->h_gens[g].size() * sizeof(HtResampleJob)));
-        HT_HIP(c, hipMemcpy(c->d_gens[g], c->h_gens[g].data(), c->h_gens[g].size() * sizeof(HtResampleJob), hipMemcpyHostToDevice));
+        c->gen_blocks[g] = (uint32_t)tiles.size();
+        if (tiles.empty()) continue;
+        HT_HIP(c, hipMalloc(&c->d_gen_blocks[g], tiles.size() * sizeof(HtResampleJob)));
+        HT_HIP(c, hipMemcpy(c->d_gen_blocks[g], tiles.data(), tiles.size() * sizeof(HtResampleJob), hipMemcpyHostToDevice));
     }
 
     HT_HIP(c, hipMalloc(&c->d_levels, sizeof(HtDevLevel) * HT_MAX_LEVELS));

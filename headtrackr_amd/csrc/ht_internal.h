@@ -82,14 +82,17 @@ struct HtDevLevel {
 };
 
 // One resample job = one canvas of the pyramid (ccv.js:121,128,135,140,145).
+// One drawImage call (host job list) and, with the tile fields filled in, one k_resample workgroup (device tile table).
+constexpr int HT_RS_SRC_ROWS = 76;   // k_resample LDS window: source rows per tile
+constexpr int HT_RS_MAX_PASSES = 4;  // k_resample: 16-row passes per tile at most
 struct HtResampleJob {
     uint32_t src_off, dst_off;
     int32_t src_stride, dst_stride;
     int32_t sx, sy, sw, sh;  // source rect
     int32_t dw, dh;          // destination rect (at 0,0)
     int32_t cw, ch;          // destination canvas size (pixels outside dw x dh are written 0)
-    uint32_t block_begin;    // first block of this job inside its generation's grid
-    uint32_t blocks_x;       // blocks per row of the canvas
+    uint16_t bx, pass0;      // tile record only: tile column (64 px), first 16-row pass
+    uint16_t np, pad;        // tile record only: number of 16-row passes (<= HT_RS_MAX_PASSES)
     double rx, ry;           // sw/dw, sh/dh computed on the host (binary64 division)
 };
 
@@ -107,8 +110,8 @@ struct HtScanScale {
 // Direct block -> work lookup (one 8-byte load per workgroup instead of a serial scan over a prefix table).
 struct HtBlockRef {
     uint16_t item;  // resample: job index in the generation; scan: index into the scale table
-    uint16_t bx, by;
-    uint16_t pad;
+    uint16_t bx, by;  // tile column / row (resample: by = first 16-row pass of the tile)
+    uint16_t pad;     // resample: number of 16-row passes in this tile; scan: unused
 };
 
 // Survivor handed from the tile kernel to the deep kernel.
@@ -178,11 +181,9 @@ struct ht_ctx {
     uint64_t pyr_bytes = 0, windows_per_frame = 0;
     uint8_t *d_arena = nullptr;
     std::vector<std::vector<HtResampleJob>> h_gens;  // generation g: jobs that only depend on generations < g
-    std::vector<HtResampleJob *> d_gens;
-    std::vector<HtBlockRef *> d_gen_blocks;  // per generation: block -> (job, bx, by)
+    std::vector<HtResampleJob *> d_gen_blocks;  // per generation: k_resample tile records (job + tile position)
     HtBlockRef *d_tile_refs = nullptr;        // per-frame tile -> (scale, tx, ty)
     std::vector<uint32_t> gen_blocks;
-    std::vector<int> gen_rpt;  // k_resample rows per thread chosen per generation (tile = 64 x 16*rpt): big tiles for big levels
     std::vector<HtScanScale> h_scales;
     HtScanScale *d_scales = nullptr;
     uint32_t tiles_per_frame = 0;

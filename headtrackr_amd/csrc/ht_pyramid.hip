@@ -139,86 +139,137 @@ __device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap (&cx)
     return o;
 }
 
+// LDS variant.  Two facts of the declared resampler make the addressing trivial: b == a + 1 unless the coordinate was
+// clamped to the last source sample, and then its weight t is exactly 0, so ANY finite neighbour gives the same rounded
+// sum (x * 0 = +0 for every byte x).  The four taps of a pixel are therefore p[0], p[1], p[pitch], p[pitch + 1] from one
+// address (ds_read_u8 with immediate offsets) whatever the clamping; s_src carries one spare row for the p[pitch] read
+// of the last staged row.  Store: round half to even via the 2^52 + 2^51 add (values are within [0, 255]).
+#ifndef HT_RS_BRANCHFREE
+#define HT_RS_BRANCHFREE 0
+#endif
+__device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int (&ia)[4], const double (&cu)[4], const double (&ct)[4],
+                                                   double ru, double rt, int npx) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (HT_RS_BRANCHFREE || k < npx) {
+            const uint8_t *p = row + ia[k];
+            const double top = __dadd_rn(__dmul_rn((double)p[0], cu[k]), __dmul_rn((double)p[1], ct[k]));
+            const double bot = __dadd_rn(__dmul_rn((double)p[RS_SP], cu[k]), __dmul_rn((double)p[RS_SP + 1], ct[k]));
+            const double vv = __dadd_rn(__dmul_rn(top, ru), __dmul_rn(bot, rt));
+            o |= (uint32_t)__double2loint(__dadd_rn(vv, 6755399441055744.0)) << (8 * k);
+        }
+    }
+    if (HT_RS_BRANCHFREE) o &= npx >= 4 ? 0xffffffffu : ((1u << (8 * max(npx, 0))) - 1u);
+    return o;
+}
+
 #ifndef HT_RS_WPS
 #define HT_RS_WPS 1
 #endif
+#ifndef HT_RS_EXPERIMENT
+#define HT_RS_EXPERIMENT 0  // timing experiments only (results are wrong): 1 = no pixel arithmetic, 2 = no source loads
+#endif
+#ifdef HT_RS_TIMELINE  // tools/micro/resample_timeline.hip: shader-clock stamps of the phases of every workgroup
+__device__ unsigned long long g_rs_timeline[1 << 16][8];
+#define RS_STAMP(i)                                                                     \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (threadIdx.x == 0) g_rs_timeline[blockIdx.x & 0xffffu][i] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#else
+#define RS_STAMP(i)
+#endif
+// One workgroup = one tile record: 64 columns x (16 * np) rows of one drawImage call, np <= RPT passes chosen per tile by
+// the host (ht_context.hip) so that (a) a level's rows are split evenly — 214 rows are 4 + 4 + 3 + 3 passes, not 4 x 4
+// with the last tile a third empty — and (b) the source rows the tile touches fit the fixed HT_RS_SRC_ROWS-row LDS
+// window (np = 4 at ratio 1.12, 2 at ratio 2).  The kernel is a latency chain (tile record -> source extent -> HBM
+// loads -> LDS -> pixels) with only LDS-many workgroups per CU to overlap it, so the chain is kept short: the record
+// carries the whole job (one scalar load), every thread derives the tile's source extent itself (four tap evaluations,
+// no LDS round trip) and issues its loads at once, and the tap tables are computed while those loads are in flight.
 template <int RPT>
-__global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob *__restrict__ jobs, const HtBlockRef *__restrict__ refs,
-                                                  uint8_t *__restrict__ arena, uint64_t arena_stride, uint32_t blocks_per_frame,
-                                                  uint32_t nframes) {
-    constexpr int TH = 16 * RPT;               // destination rows per tile
-    constexpr int SR = 2 * TH + TH / 16 + 6;   // LDS source rows (ratio <= 2.04 plus the tap pair)
-    __shared__ __attribute__((aligned(16))) uint8_t s_src[SR * RS_SP];
+__global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob *__restrict__ tiles, uint8_t *__restrict__ arena,
+                                                  uint64_t arena_stride, uint32_t blocks_per_frame, uint32_t nframes) {
+    constexpr int TH = 16 * RPT;          // destination rows per tile (at most)
+    constexpr int SR = HT_RS_SRC_ROWS;    // LDS source rows
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[(SR + 1) * RS_SP + 16];
     __shared__ RsTap s_col[RS_TW], s_row[TH];
     uint32_t fidx, blk;
     if (!xcd_item(blocks_per_frame, nframes, &fidx, &blk)) return;
-    const HtBlockRef ref = refs[blk];  // block -> (job, tile x, tile y): one scalar load
-    const HtResampleJob &J = jobs[ref.item];
+    RS_STAMP(0);
+    const HtResampleJob &J = tiles[blk];
     const int tid = (int)threadIdx.x;
-    const int X0 = (int)ref.bx * RS_TW, Y0 = (int)ref.by * TH;
+    const int np = (int)J.np;
+    const int X0 = (int)J.bx * RS_TW, Y0 = (int)J.pass0 * 16;
     uint8_t *frame = arena + (uint64_t)fidx * arena_stride;
     const uint8_t *src = frame + J.src_off;
-    const int ncols = min(RS_TW, J.dw - X0), nrows = min(TH, J.dh - Y0);  // drawn part of this tile (may be <= 0)
-    const int x0 = X0 + (tid & 15) * 4, yt = Y0 + (tid >> 4);              // this thread: rows yt, yt+16, ...
+    const int ncols = min(RS_TW, J.dw - X0), nrows = min(16 * np, J.dh - Y0);  // drawn part of this tile (may be <= 0)
+    const int x0 = X0 + (tid & 15) * 4, yt = Y0 + (tid >> 4);                  // this thread: rows yt, yt+16, ...
     uint32_t o[RPT];
 #pragma unroll
     for (int q = 0; q < RPT; q++) o[q] = 0;
     if (ncols > 0 && nrows > 0) {
-        if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
-        if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
-        __syncthreads();
-        const int xa = s_col[0].a & ~3, xb = s_col[ncols - 1].b, ya = s_row[0].a, yb = s_row[nrows - 1].b;
-        const int sw4 = (xb - xa) / 4 + 1, sh = yb - ya + 1;  // dwords per row, rows
-        const bool in_lds = (sw4 * 4 <= RS_SP) && (sh <= SR);
+        const int xa = rs_tap(X0, J.rx, J.sw, J.sx).a & ~15, xb = rs_tap(X0 + ncols - 1, J.rx, J.sw, J.sx).b;
+        const int ya = rs_tap(Y0, J.ry, J.sh, J.sy).a, yb = rs_tap(Y0 + nrows - 1, J.ry, J.sh, J.sy).b;
+        const int sw16 = (xb - xa) / 16 + 1;  // 16-byte chunks per source row
+        const int sh = yb - ya + 1;           // source rows
+        const bool in_lds = (sw16 * 16 <= RS_SP) && (sh <= SR);
         const int npx = min(4, J.dw - x0);
         if (in_lds) {
-            // source rows as aligned dwords, all loads issued before the first LDS write.  8 threads share a row (5
-            // consecutive dwords each = the 160-byte LDS pitch), 32 rows per pass: the index arithmetic is one add per
-            // pass instead of a division per dword (the staging loop used to be as long as the pixel arithmetic itself).
-            constexpr int KR = (SR + 31) / 32;
-            const int r0 = tid >> 3, cg = (tid & 7) * 5;
-            const uint8_t *sbase = src + (size_t)ya * J.src_stride + xa + 4 * cg;
-            uint32_t v[KR][5];
+            // source rows as 16-byte chunks, all loads issued before anything else.  10 threads share a row (= the
+            // 160-byte LDS pitch), 25 rows per pass.  Plane strides are only 4-byte multiples, so the chunks are dword-
+            // not 16-byte-aligned in HBM and may run past the row's end into the next row / plane of the same arena
+            // (never used: see rs_pixels4_lds).  Loads are unconditional with clamped coordinates (duplicates fall into
+            // cache lines the wave fetches anyway); only the LDS writes are predicated.
+            constexpr int KR = (SR + 24) / 25;
+            const int r0 = (tid * 205) >> 11, c16 = tid - r0 * 10;  // tid / 10, tid % 10 for tid < 256
+            const bool lane_on = (r0 < 25) && (c16 < sw16);
+            const uint8_t *sbase = src + (size_t)ya * J.src_stride + xa + 16 * min(c16, sw16 - 1);
+            uint4 v[KR];
 #pragma unroll
-            for (int k = 0; k < KR; k++) {
-                const int r = r0 + 32 * k;
-                const uint32_t *rowp = reinterpret_cast<const uint32_t *>(sbase + (size_t)r * J.src_stride);
+            for (int k = 0; k < KR; k++)
+                if (HT_RS_EXPERIMENT != 2) v[k] = *reinterpret_cast<const uint4 *>(sbase + (size_t)min(r0 + 25 * k, sh - 1) * J.src_stride);
+            RS_STAMP(1);
+            if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
+            if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
+            RS_STAMP(2);
 #pragma unroll
-                for (int j = 0; j < 5; j++) {
-                    v[k][j] = 0;
-                    if (r < sh && cg + j < sw4) v[k][j] = rowp[j];
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < KR; k++) {
-                const int r = r0 + 32 * k;
-                if (r < SR) {
-                    uint32_t *dstp = reinterpret_cast<uint32_t *>(&s_src[r * RS_SP + 4 * cg]);
-#pragma unroll
-                    for (int j = 0; j < 5; j++) dstp[j] = v[k][j];
-                }
-            }
+            for (int k = 0; k < KR; k++)
+                if (lane_on && r0 + 25 * k < sh) *reinterpret_cast<uint4 *>(&s_src[(r0 + 25 * k) * RS_SP + 16 * c16]) = v[k];
+            RS_STAMP(3);
             __syncthreads();
-            RsTap cx[4];
+            RS_STAMP(4);
+            int ia[4];
+            double cu[4], ct[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) cx[k] = s_col[min(x0 - X0 + k, ncols - 1)];
+            for (int k = 0; k < 4; k++) {
+                const RsTap tp = s_col[min(x0 - X0 + k, ncols - 1)];
+                ia[k] = tp.a - xa, cu[k] = tp.u, ct[k] = tp.t;
+            }
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
                 const int y = yt + 16 * q;
-                if (y < J.dh && npx > 0) {
+                if (q < np && y < J.dh && npx > 0) {
                     const RsTap ry = s_row[y - Y0];
-                    o[q] = rs_pixels4<const uint8_t *>(s_src + (ry.a - ya) * RS_SP, s_src + (ry.b - ya) * RS_SP, cx, ry, xa, npx);
+                    if (HT_RS_EXPERIMENT == 1) o[q] = *reinterpret_cast<const uint32_t *>(s_src + (ry.a - ya) * RS_SP + (ia[0] & ~3));
+                    else o[q] = rs_pixels4_lds(s_src + (ry.a - ya) * RS_SP, ia, cu, ct, ry.u, ry.t, npx);
                 }
             }
-        } else {
+#ifdef HT_RS_TIMELINE
+#pragma unroll
+            for (int q = 0; q < RPT; q++) asm volatile("" ::"v"(o[q]));
+            RS_STAMP(5);
+#endif
+        } else {  // source span larger than the LDS window (ratios > 2.3: the last 1-3 pixel levels): taps straight from HBM
             RsTap cx[4];
 #pragma unroll
-            for (int k = 0; k < 4; k++) cx[k] = s_col[min(x0 - X0 + k, ncols - 1)];
+            for (int k = 0; k < 4; k++) cx[k] = rs_tap(min(x0 + k, X0 + ncols - 1), J.rx, J.sw, J.sx);
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
                 const int y = yt + 16 * q;
-                if (y < J.dh && npx > 0) {
-                    const RsTap ry = s_row[y - Y0];
+                if (q < np && y < J.dh && npx > 0) {
+                    const RsTap ry = rs_tap(y, J.ry, J.sh, J.sy);
                     o[q] = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * J.src_stride, src + (size_t)ry.b * J.src_stride, cx, ry, 0, npx);
                 }
             }
@@ -228,8 +279,9 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
 #pragma unroll
     for (int q = 0; q < RPT; q++) {
         const int y = yt + 16 * q;
-        if (y < J.ch && x0 < J.dst_stride) *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o[q];
+        if (q < np && y < J.ch && x0 < J.dst_stride) *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o[q];
     }
+    RS_STAMP(6);
 }
 
 // per-frame channel sums for getWhitebalance; out[f*4 + c] (u64), zeroed by the host
@@ -289,15 +341,8 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         if (c->gen_blocks[g] == 0) continue;
         HtProfScope ps(c, "resample");
         const dim3 rgrid((c->gen_blocks[g] * (uint32_t)c->nframes + 7u) & ~7u);
-        if (c->gen_rpt[g] == 4)
-            hipLaunchKernelGGL(k_resample<4>, rgrid, dim3(256), 0, c->stream, c->d_gens[g], c->d_gen_blocks[g], c->d_arena,
-                               c->arena_stride, c->gen_blocks[g], (uint32_t)c->nframes);
-        else if (c->gen_rpt[g] == 2)
-            hipLaunchKernelGGL(k_resample<2>, rgrid, dim3(256), 0, c->stream, c->d_gens[g], c->d_gen_blocks[g], c->d_arena,
-                               c->arena_stride, c->gen_blocks[g], (uint32_t)c->nframes);
-        else
-            hipLaunchKernelGGL(k_resample<1>, rgrid, dim3(256), 0, c->stream, c->d_gens[g], c->d_gen_blocks[g], c->d_arena,
-                               c->arena_stride, c->gen_blocks[g], (uint32_t)c->nframes);
+        hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,
+                           c->gen_blocks[g], (uint32_t)c->nframes);
         HT_HIP(c, hipGetLastError());
     }
     return HT_OK;

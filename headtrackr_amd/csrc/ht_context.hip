@@ -217,6 +217,11 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         const int v = atoi(e);
         if (v >= 1 && v <= HT_RS_MAX_PASSES) c->rs_rpt = v;
     }
+    if (const char *e = getenv("HT_DEBUG_RS_MINWG")) c->rs_min_wgs = std::max(1, atoi(e));  // measurement knob
+    if (const char *e = getenv("HT_DEBUG_RS_GROUP")) {  // measurement knob
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) c->rs_group = v;
+    }
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
     c->split_stage = std::min<uint32_t>(c->builtin_cascade ? 8u : 4u, c->nstages);
@@ -411,6 +416,16 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
                 pass0 += np;
             }
         }
+        // launch order = source order: tiles of different drawImage calls that read the same rows of the same source
+        // plane (levels 1..6 all read level 0; the four variants of a level read the same parent) run back to back on
+        // an XCD, so the source band is fetched from HBM once and then served by that XCD's L2
+        if (!getenv("HT_DEBUG_RS_NOSORT"))
+            std::stable_sort(tiles.begin(), tiles.end(), [](const HtResampleJob &a, const HtResampleJob &b) {
+                if (a.src_off != b.src_off) return a.src_off < b.src_off;
+                const int ya = (int)(16.0 * a.pass0 * a.ry), yb = (int)(16.0 * b.pass0 * b.ry);
+                if (ya / 32 != yb / 32) return ya < yb;
+                return a.bx < b.bx;
+            });
         c->gen_blocks[g] = (uint32_t)tiles.size();
         if (tiles.empty()) continue;
         HT_HIP(c, hipMalloc(&c->d_gen_blocks[g], tiles.size() * sizeof(HtResampleJob)));

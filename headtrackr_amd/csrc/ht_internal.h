@@ -187,6 +187,8 @@ struct ht_ctx {
     std::vector<HtScanScale> h_scales;
     HtScanScale *d_scales = nullptr;
     uint32_t tiles_per_frame = 0;
+    int rs_min_wgs = 2048;  // ... but never fewer workgroups per launch than this (HT_DEBUG_RS_MINWG)
+    int rs_group = 8;  // k_resample: frames per workgroup at most (HT_DEBUG_RS_GROUP)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
 
     // frames

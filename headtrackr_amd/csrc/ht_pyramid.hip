@@ -181,76 +181,101 @@ __device__ unsigned long long g_rs_timeline[1 << 16][8];
 #else
 #define RS_STAMP(i)
 #endif
-// One workgroup = one tile record: 64 columns x (16 * np) rows of one drawImage call, np <= RPT passes chosen per tile by
-// the host (ht_context.hip) so that (a) a level's rows are split evenly — 214 rows are 4 + 4 + 3 + 3 passes, not 4 x 4
-// with the last tile a third empty — and (b) the source rows the tile touches fit the fixed HT_RS_SRC_ROWS-row LDS
-// window (np = 4 at ratio 1.12, 2 at ratio 2).  The kernel is a latency chain (tile record -> source extent -> HBM
-// loads -> LDS -> pixels) with only LDS-many workgroups per CU to overlap it, so the chain is kept short: the record
-// carries the whole job (one scalar load), every thread derives the tile's source extent itself (four tap evaluations,
-// no LDS round trip) and issues its loads at once, and the tap tables are computed while those loads are in flight.
+// One workgroup = one tile record x one group of K consecutive frames.  A tile is 64 columns x (16 * np) rows of one
+// drawImage call, np <= RPT passes chosen per tile by the host (ht_context.hip) so that (a) a level's rows are split
+// evenly — 214 rows are 4 + 4 + 3 + 3 passes, not 4 x 4 with the last tile a third empty — and (b) the source rows the
+// tile touches fit the fixed HT_RS_SRC_ROWS-row LDS window (np = 4 at ratio 1.12, 2 at ratio 2).
+//
+// Measured with tools/micro/resample_timeline.hip: a workgroup that does one tile of one frame is a pure latency chain —
+// record + extent + load issue 31 %, waiting for the loads 25 %, pixels 29 % — and a CU holds too few of them to overlap
+// it.  Every frame of a batch has the same geometry, so a workgroup keeps its tile for K frames instead: record, source
+// extent and tap tables are computed once, and the source tile of frame f+1 is loaded (into registers) while the pixels
+// of frame f are computed from LDS.  Frames of a group are consecutive, so they stay inside one XCD's share of the batch.
 template <int RPT>
 __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob *__restrict__ tiles, uint8_t *__restrict__ arena,
-                                                  uint64_t arena_stride, uint32_t blocks_per_frame, uint32_t nframes) {
+                                                  uint64_t arena_stride, uint32_t blocks_per_frame, uint32_t ngroups,
+                                                  uint32_t nframes, uint32_t group_frames) {
     constexpr int TH = 16 * RPT;          // destination rows per tile (at most)
     constexpr int SR = HT_RS_SRC_ROWS;    // LDS source rows
     __shared__ __attribute__((aligned(16))) uint8_t s_src[(SR + 1) * RS_SP + 16];
     __shared__ RsTap s_col[RS_TW], s_row[TH];
-    uint32_t fidx, blk;
-    if (!xcd_item(blocks_per_frame, nframes, &fidx, &blk)) return;
+    uint32_t gidx, blk;
+    if (!xcd_item(blocks_per_frame, ngroups, &gidx, &blk)) return;
     RS_STAMP(0);
     const HtResampleJob &J = tiles[blk];
+    const uint32_t f0 = gidx * group_frames, f1 = min(f0 + group_frames, nframes);
     const int tid = (int)threadIdx.x;
     const int np = (int)J.np;
     const int X0 = (int)J.bx * RS_TW, Y0 = (int)J.pass0 * 16;
-    uint8_t *frame = arena + (uint64_t)fidx * arena_stride;
-    const uint8_t *src = frame + J.src_off;
+    uint8_t *frame = arena + (uint64_t)f0 * arena_stride;
     const int ncols = min(RS_TW, J.dw - X0), nrows = min(16 * np, J.dh - Y0);  // drawn part of this tile (may be <= 0)
     const int x0 = X0 + (tid & 15) * 4, yt = Y0 + (tid >> 4);                  // this thread: rows yt, yt+16, ...
-    uint32_t o[RPT];
+    const int npx = min(4, J.dw - x0);
+    const bool drawn = ncols > 0 && nrows > 0;
+    int xa = 0, ya = 0, sw16 = 1, sh = 1;
+    bool in_lds = false;
+    if (drawn) {
+        xa = rs_tap(X0, J.rx, J.sw, J.sx).a & ~15;
+        ya = rs_tap(Y0, J.ry, J.sh, J.sy).a;
+        sw16 = (rs_tap(X0 + ncols - 1, J.rx, J.sw, J.sx).b - xa) / 16 + 1;  // 16-byte chunks per source row
+        sh = rs_tap(Y0 + nrows - 1, J.ry, J.sh, J.sy).b - ya + 1;           // source rows
+        in_lds = (sw16 * 16 <= RS_SP) && (sh <= SR);
+    }
+    if (in_lds) {
+        // source rows as 16-byte chunks.  10 threads share a row (= the 160-byte LDS pitch), 25 rows per pass.  Plane
+        // strides are only 4-byte multiples, so the chunks are dword- not 16-byte-aligned in HBM and may run past the
+        // row's end into the next row / plane of the same arena (never used: see rs_pixels4_lds).  Loads are
+        // unconditional with clamped coordinates (duplicates fall into cache lines the wave fetches anyway); only the
+        // LDS writes are predicated.
+        constexpr int KR = (SR + 24) / 25;
+        const int r0 = (tid * 205) >> 11, c16 = tid - r0 * 10;  // tid / 10, tid % 10 for tid < 256
+        const bool lane_on = (r0 < 25) && (c16 < sw16);
+        // addresses = uniform frame base (scalar registers) + 32-bit per-thread offsets
+        const uint32_t soff = J.src_off + (uint32_t)(ya * J.src_stride + xa + 16 * min(c16, sw16 - 1));
+        static_assert(KR == 4, "the staging registers below are written out for four passes");
+        const uint32_t soff0 = soff + (uint32_t)(min(r0, sh - 1) * J.src_stride), soff1 = soff + (uint32_t)(min(r0 + 25, sh - 1) * J.src_stride);
+        const uint32_t soff2 = soff + (uint32_t)(min(r0 + 50, sh - 1) * J.src_stride), soff3 = soff + (uint32_t)(min(r0 + 75, sh - 1) * J.src_stride);
+        uint4 v0, v1, v2, v3;  // named scalars: an array assigned under `if (f + 1 < f1)` is demoted to scratch
+#define RS_LOAD_TILE(base)                                              \
+    do {                                                                \
+        v0 = *reinterpret_cast<const uint4 *>((base) + soff0);          \
+        v1 = *reinterpret_cast<const uint4 *>((base) + soff1);          \
+        v2 = *reinterpret_cast<const uint4 *>((base) + soff2);          \
+        v3 = *reinterpret_cast<const uint4 *>((base) + soff3);          \
+    } while (0)
+        RS_LOAD_TILE(frame);
+        if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
+        if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
+        __syncthreads();
+        RS_STAMP(1);
+        int ia[4];
+        double cu[4], ct[4];
 #pragma unroll
-    for (int q = 0; q < RPT; q++) o[q] = 0;
-    if (ncols > 0 && nrows > 0) {
-        const int xa = rs_tap(X0, J.rx, J.sw, J.sx).a & ~15, xb = rs_tap(X0 + ncols - 1, J.rx, J.sw, J.sx).b;
-        const int ya = rs_tap(Y0, J.ry, J.sh, J.sy).a, yb = rs_tap(Y0 + nrows - 1, J.ry, J.sh, J.sy).b;
-        const int sw16 = (xb - xa) / 16 + 1;  // 16-byte chunks per source row
-        const int sh = yb - ya + 1;           // source rows
-        const bool in_lds = (sw16 * 16 <= RS_SP) && (sh <= SR);
-        const int npx = min(4, J.dw - x0);
-        if (in_lds) {
-            // source rows as 16-byte chunks, all loads issued before anything else.  10 threads share a row (= the
-            // 160-byte LDS pitch), 25 rows per pass.  Plane strides are only 4-byte multiples, so the chunks are dword-
-            // not 16-byte-aligned in HBM and may run past the row's end into the next row / plane of the same arena
-            // (never used: see rs_pixels4_lds).  Loads are unconditional with clamped coordinates (duplicates fall into
-            // cache lines the wave fetches anyway); only the LDS writes are predicated.
-            constexpr int KR = (SR + 24) / 25;
-            const int r0 = (tid * 205) >> 11, c16 = tid - r0 * 10;  // tid / 10, tid % 10 for tid < 256
-            const bool lane_on = (r0 < 25) && (c16 < sw16);
-            const uint8_t *sbase = src + (size_t)ya * J.src_stride + xa + 16 * min(c16, sw16 - 1);
-            uint4 v[KR];
-#pragma unroll
-            for (int k = 0; k < KR; k++)
-                if (HT_RS_EXPERIMENT != 2) v[k] = *reinterpret_cast<const uint4 *>(sbase + (size_t)min(r0 + 25 * k, sh - 1) * J.src_stride);
-            RS_STAMP(1);
-            if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
-            if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
+        for (int k = 0; k < 4; k++) {
+            const RsTap tp = s_col[min(x0 - X0 + k, ncols - 1)];
+            ia[k] = tp.a - xa, cu[k] = tp.u, ct[k] = tp.t;
+        }
+        const int dh = J.dh, ch = J.ch, dst_stride = J.dst_stride;  // locals: not re-read from the record after each store
+        const uint32_t doff = J.dst_off + (uint32_t)(yt * dst_stride + x0);
+        for (uint32_t f = f0; f < f1; f++, frame += arena_stride) {
             RS_STAMP(2);
-#pragma unroll
-            for (int k = 0; k < KR; k++)
-                if (lane_on && r0 + 25 * k < sh) *reinterpret_cast<uint4 *>(&s_src[(r0 + 25 * k) * RS_SP + 16 * c16]) = v[k];
+            uint8_t *sdst = &s_src[r0 * RS_SP + 16 * c16];
+            if (lane_on && r0 < sh) *reinterpret_cast<uint4 *>(sdst) = v0;
+            if (lane_on && r0 + 25 < sh) *reinterpret_cast<uint4 *>(sdst + 25 * RS_SP) = v1;
+            if (lane_on && r0 + 50 < sh) *reinterpret_cast<uint4 *>(sdst + 50 * RS_SP) = v2;
+            if (lane_on && r0 + 75 < sh) *reinterpret_cast<uint4 *>(sdst + 75 * RS_SP) = v3;
             RS_STAMP(3);
             __syncthreads();
             RS_STAMP(4);
-            int ia[4];
-            double cu[4], ct[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const RsTap tp = s_col[min(x0 - X0 + k, ncols - 1)];
-                ia[k] = tp.a - xa, cu[k] = tp.u, ct[k] = tp.t;
+            if (f + 1 < f1) {  // next frame's source tile: in flight during this frame's pixels
+                RS_LOAD_TILE(frame + arena_stride);
             }
+            uint32_t o[RPT];
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
                 const int y = yt + 16 * q;
-                if (q < np && y < J.dh && npx > 0) {
+                o[q] = 0;
+                if (q < np && y < dh && npx > 0) {
                     const RsTap ry = s_row[y - Y0];
                     if (HT_RS_EXPERIMENT == 1) o[q] = *reinterpret_cast<const uint32_t *>(s_src + (ry.a - ya) * RS_SP + (ia[0] & ~3));
                     else o[q] = rs_pixels4_lds(s_src + (ry.a - ya) * RS_SP, ia, cu, ct, ry.u, ry.t, npx);
@@ -261,27 +286,35 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
             for (int q = 0; q < RPT; q++) asm volatile("" ::"v"(o[q]));
             RS_STAMP(5);
 #endif
-        } else {  // source span larger than the LDS window (ratios > 2.3: the last 1-3 pixel levels): taps straight from HBM
-            RsTap cx[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) cx[k] = rs_tap(min(x0 + k, X0 + ncols - 1), J.rx, J.sw, J.sx);
+            // pixels outside the drawn dw x dh rect stay transparent black (ccv.js:135-145 draws 2 px short on the variants)
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
                 const int y = yt + 16 * q;
-                if (q < np && y < J.dh && npx > 0) {
-                    const RsTap ry = rs_tap(y, J.ry, J.sh, J.sy);
-                    o[q] = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * J.src_stride, src + (size_t)ry.b * J.src_stride, cx, ry, 0, npx);
-                }
+                if (q < np && y < ch && x0 < dst_stride) *reinterpret_cast<uint32_t *>(frame + (doff + (uint32_t)(16 * q * dst_stride))) = o[q];
             }
+            if (f + 1 < f1) __syncthreads();  // every wave is done reading this frame's tile
+            RS_STAMP(6);
+        }
+        return;
+    }
+    // nothing drawn in this tile (transparent black), or a source span larger than the LDS window (ratios > 2.3: the
+    // last 1-3 pixel levels): taps straight from HBM
+    RsTap cx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cx[k] = rs_tap(min(x0 + k, X0 + max(ncols, 1) - 1), J.rx, J.sw, J.sx);
+    for (uint32_t f = f0; f < f1; f++, frame += arena_stride) {
+        const uint8_t *src = frame + J.src_off;
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+            const int y = yt + 16 * q;
+            uint32_t o = 0;
+            if (drawn && q < np && y < J.dh && npx > 0) {
+                const RsTap ry = rs_tap(y, J.ry, J.sh, J.sy);
+                o = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * J.src_stride, src + (size_t)ry.b * J.src_stride, cx, ry, 0, npx);
+            }
+            if (q < np && y < J.ch && x0 < J.dst_stride) *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o;
         }
     }
-    // pixels outside the drawn dw x dh rect stay transparent black (ccv.js:135-145 draws 2 px short on the variants)
-#pragma unroll
-    for (int q = 0; q < RPT; q++) {
-        const int y = yt + 16 * q;
-        if (q < np && y < J.ch && x0 < J.dst_stride) *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o[q];
-    }
-    RS_STAMP(6);
 }
 
 // per-frame channel sums for getWhitebalance; out[f*4 + c] (u64), zeroed by the host
@@ -340,9 +373,16 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
     for (size_t g = 1; g < c->h_gens.size(); g++) {
         if (c->gen_blocks[g] == 0) continue;
         HtProfScope ps(c, "resample");
-        const dim3 rgrid((c->gen_blocks[g] * (uint32_t)c->nframes + 7u) & ~7u);
+        // frames per workgroup: as many as keep >= ~4 workgroups per CU slot in the launch, at most rs_group; groups never
+        // straddle the 8 XCD shares of the batch when the batch is a multiple of 8 * K
+        uint32_t K = 1;
+        while (K * 2 <= (uint32_t)c->rs_group && (uint64_t)c->gen_blocks[g] * ((uint32_t)c->nframes / (K * 2)) >= (uint64_t)c->rs_min_wgs &&
+               (uint32_t)c->nframes % (K * 2 * 8) == 0)
+            K *= 2;
+        const uint32_t ngroups = ((uint32_t)c->nframes + K - 1) / K;
+        const dim3 rgrid((c->gen_blocks[g] * ngroups + 7u) & ~7u);
         hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,
-                           c->gen_blocks[g], (uint32_t)c->nframes);
+                           c->gen_blocks[g], ngroups, (uint32_t)c->nframes, K);
         HT_HIP(c, hipGetLastError());
     }
     return HT_OK;

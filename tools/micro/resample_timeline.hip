@@ -15,6 +15,7 @@ ht_status ht_fail(ht_ctx *, ht_status st, const std::string &) { return st; }
 int main(int argc, char **argv) {
     const int W = argc > 1 ? atoi(argv[1]) : 320, H = argc > 2 ? atoi(argv[2]) : 240, N = argc > 3 ? atoi(argv[3]) : 256;
     const int npmax_cap = argc > 4 ? atoi(argv[4]) : HT_RS_MAX_PASSES;
+    const uint32_t K = argc > 5 ? atoi(argv[5]) : 1;
     std::vector<HtResampleJob> tiles;
     size_t off = 0;
     auto plane = [&](int w, int h, int *stride) { *stride = (w + 3) & ~3; size_t o = off; off = (off + (size_t)*stride * h + 255) & ~(size_t)255; return o; };
@@ -45,12 +46,13 @@ int main(int argc, char **argv) {
     hipMalloc(&d_tiles, tiles.size() * sizeof(HtResampleJob));
     hipMemcpy(d_tiles, tiles.data(), tiles.size() * sizeof(HtResampleJob), hipMemcpyHostToDevice);
     const uint32_t bpf = (uint32_t)tiles.size();
-    const dim3 grid((bpf * N + 7u) & ~7u);
+    const uint32_t ngroups = (N + K - 1) / K;
+    const dim3 grid((bpf * ngroups + 7u) & ~7u);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     float best = 1e9f;
     for (int rep = 0; rep < 5; rep++) {
         hipEventRecord(a);
-        hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, grid, dim3(256), 0, 0, d_tiles, arena, arena_stride, bpf, (uint32_t)N);
+        hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, grid, dim3(256), 0, 0, d_tiles, arena, arena_stride, bpf, ngroups, (uint32_t)N, K);
         hipEventRecord(b); hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b); best = std::min(best, ms);
     }
@@ -58,7 +60,7 @@ int main(int argc, char **argv) {
     static unsigned long long tl[1 << 16][8];
     hipMemcpyFromSymbol(tl, HIP_SYMBOL(g_rs_timeline), sizeof(tl));
     const int nb = std::min<int>(grid.x, 1 << 16);
-    const char *names[6] = {"record+extent+issue loads", "taps", "wait loads + LDS write", "barrier", "pixels", "stores issued"};
+    const char *names[6] = {"prologue (record, extent, loads, taps)", "taps -> registers / earlier frames", "LAST FRAME: wait loads + LDS write", "  barrier", "  issue next loads + pixels", "  stores + barrier"};
     unsigned long long tmin = ~0ull, tmax = 0;
     double sum[6] = {0}; int cnt = 0;
     for (int i = 0; i < nb; i++) {
@@ -69,7 +71,7 @@ int main(int argc, char **argv) {
     }
     printf("stamped workgroups %d, span %.1f us at 100 MHz-equivalent? (raw ticks %llu)\n", cnt, 0.0, tmax - tmin);
     double tot = 0; for (int k = 0; k < 6; k++) tot += sum[k] / cnt;
-    for (int k = 0; k < 6; k++) printf("  %-28s %9.0f ticks  %5.1f %%\n", names[k], sum[k] / cnt, 100.0 * sum[k] / cnt / tot);
-    printf("  %-28s %9.0f ticks per workgroup; kernel span %llu ticks => tick = %.3f ns\n", "total", tot, tmax - tmin, best * 1e6 / (double)(tmax - tmin));
+    for (int k = 0; k < 6; k++) printf("  %-40s %9.0f ticks  %5.1f %%\n", names[k], sum[k] / cnt, 100.0 * sum[k] / cnt / tot);
+    printf("  %-40s %9.0f ticks per workgroup; kernel span %llu ticks => tick = %.3f ns\n", "total", tot, tmax - tmin, best * 1e6 / (double)(tmax - tmin));
     return 0;
 }

@@ -298,7 +298,26 @@ def main():
         ctx.detect_enqueue(a.flags | 16)  # one extra untimed pass with HT_SCAN_STATS for the survival curve
         ctx.detect_collect(cap=1 << 16)
         sc = ctx.stage_counts()
-        extra = dict(kernel_ms_per_step={k: round(v, 5) for k, v in per_step.items()}, kernel_rooflines=kernel_rooflines,
+        # a device-copy ceiling measured in the same run (what a kernel that only reads and writes HBM
+        # reaches on this box), and feature evaluations per second from the survival curve
+        buf = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+        dst = torch.empty_like(buf)
+        dst.copy_(buf)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(8):
+            dst.copy_(buf)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * buf.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del buf, dst
+        roofline["device_copy_gbs"] = round(copy_gbs, 1)
+        roofline["frac_of_device_copy"] = round(achieved / copy_gbs, 5)
+        per_stage = [int(v) for v in ctx.cascade.stages["count"]]
+        feat_evals = sum(int(sc[j]) * per_stage[j] for j in range(len(per_stage)))
+        extra = dict(feature_evals_per_s=round(feat_evals / (dev_ms * 1e-3), 1),
+                     kernel_ms_per_step={k: round(v, 5) for k, v in per_step.items()}, kernel_rooflines=kernel_rooflines,
                      device_ms_per_step=round(dev_ms, 5),
                      path_hbm_gbs=round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2),
                      path_hbm_frac=round(b_detect * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),

@@ -225,6 +225,8 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
     c->split_stage = std::min<uint32_t>(c->builtin_cascade ? 8u : 4u, c->nstages);
+    if (const char *e = getenv("HT_DEBUG_SPLIT"))  // measurement knob: hand-off stage (<= 8 for the generated stage code)
+        c->split_stage = std::min<uint32_t>((uint32_t)std::max(1, atoi(e)), std::min<uint32_t>(c->builtin_cascade ? 8u : c->nstages, c->nstages));
     if ((st = upload_cascade(c)) != HT_OK) return bail(st);
     if ((st = ht_scan_pack_deep(c)) != HT_OK) return bail(st);
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), sizeof(HtCounters) + (size_t)HT_PINNED_HITS * sizeof(ht_hit), hipHostMallocDefault) != hipSuccess ||

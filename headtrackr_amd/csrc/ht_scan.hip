@@ -1042,7 +1042,6 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
         HT_HIP(c, hipGetLastError());
         return HT_OK;
     }
-    if (const char *e = getenv("HT_DEBUG_SPLIT")) c->split_stage = (uint32_t)std::max(1, atoi(e));  // measurement knob
     const int split = (flags & HT_SCAN_NO_SPLIT) ? (int)c->nstages : (int)std::min<uint32_t>(c->split_stage, c->nstages);
     const uint64_t total64 = (uint64_t)c->tiles_per_frame * (uint64_t)c->nframes;
     if (total64 > 0x7fffff00ull) return ht_fail(c, HT_ERR_INVALID, "ht_detect: batch too large for one launch");

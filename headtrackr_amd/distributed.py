@@ -20,15 +20,28 @@ def shard_range(n_total: int, rank: int, world: int):
 
 
 def pack_records(hits: np.ndarray, counts: np.ndarray, nframes: int) -> np.ndarray:
+    """Per-frame best raw hit (first maximum of `sum`, like the reference's strict '>' scan) as [nframes, 8] float64.
+    `hits` is sorted by frame, `counts[f]` hits belong to frame f.  Vectorised: this runs once per step on every rank."""
     rec = np.zeros((nframes, RECORD_F64), dtype=np.float64)
-    k = 0
-    for f in range(nframes):
-        c = int(counts[f])
-        if c:
-            h = hits[k : k + c]
-            b = h[int(np.argmax(h["sum"]))]  # first maximum, like the reference's strict '>' scan
-            rec[f, :6] = (c, b["scale"], b["q"], b["x"], b["y"], b["sum"])
-        k += c
+    cnt = np.asarray(counts[:nframes], dtype=np.int64)
+    nz = np.nonzero(cnt)[0]
+    if nz.size == 0:
+        return rec
+    starts = np.cumsum(cnt) - cnt
+    total = int(cnt.sum())
+    s = np.asarray(hits["sum"][:total], dtype=np.float64)
+    seg = np.repeat(np.arange(nz.size), cnt[nz])      # hit -> index of its (non-empty) frame
+    mx = np.maximum.reduceat(s, starts[nz])            # per-frame maximum
+    cand = np.nonzero(s == mx[seg])[0]                 # hits that reach it, in hit order
+    first = np.full(nz.size, total, dtype=np.int64)
+    np.minimum.at(first, seg[cand], cand)              # the first one per frame
+    b = hits[first]
+    rec[nz, 0] = cnt[nz]
+    rec[nz, 1] = b["scale"]
+    rec[nz, 2] = b["q"]
+    rec[nz, 3] = b["x"]
+    rec[nz, 4] = b["y"]
+    rec[nz, 5] = b["sum"]
     return rec
 
 

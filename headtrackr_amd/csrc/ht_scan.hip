@@ -45,15 +45,15 @@ constexpr int TYH = HT_TILE_TYH;        // tile height in half-window steps Y'
 #define HT_TILE_NT 256
 #endif
 constexpr int NT = HT_TILE_NT;          // threads per workgroup (256: 4 waves/SIMD at <=128 VGPRs; 512: 8 waves/SIMD at <=64)
-constexpr int PITCH0 = 2 * TXH + 24;    // 152: plane-0 bytes per LDS row
+constexpr int PITCH0 = (2 * TXH + 24 + 15) & ~15;  // 160: plane-0 bytes per LDS row (152 needed; a multiple of 16 so rows are staged in 16-byte chunks)
 constexpr int ROWS0 = 2 * TYH + 22;     // 86
-constexpr int P0_BYTES = PITCH0 * ROWS0;  // 13072
+constexpr int P0_BYTES = PITCH0 * ROWS0;  // 13760
 constexpr int GH = TYH + 11;               // plane-1 / plane-2 half-step grid: 75 x 43 cells of 2 bytes
-constexpr int G_PITCH = 2 * PITCH0;          // 304
+constexpr int G_PITCH = 2 * PITCH0;          // 320
 constexpr int P12_BASE = P0_BYTES;
-constexpr int LDS_TILE_BYTES = P0_BYTES + GH * G_PITCH;  // 26144
+constexpr int LDS_TILE_BYTES = P0_BYTES + GH * G_PITCH;  // 27520
 constexpr int MAXWIN = TXH * TYH;            // 2048 windows per tile
-static_assert(PITCH0 % 4 == 0 && P0_BYTES % 4 == 0, "alignment");
+static_assert(PITCH0 % 16 == 0 && P0_BYTES % 16 == 0, "alignment");
 
 // unified-base LDS offsets of a feature point (x, y) on plane 0 / 1 / 2, relative to the window base B
 #define HT_O0(x, y) ((y) * PITCH0 + (x))                      // level i:        1 B/px, row pitch P
@@ -164,61 +164,70 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 
     // ---- stage the three planes into LDS --------------------------------------------------------------------
     // All global loads of a thread are issued before the first LDS write (fixed trip counts, predicated), so one
-    // memory latency is paid per tile instead of one per loop iteration; everything is loaded as aligned dwords /
-    // halfwords (tile origins are multiples of 4 half-steps).
+    // memory latency is paid per tile instead of one per loop iteration.  Wide accesses: 16-byte chunks of level i, and
+    // per 8 half-step cells 8 bytes of level i+6 plus 4 bytes of each of the row's two variants (tile origins are
+    // multiples of 8 half-steps) — 10 loads per thread instead of 25 dword-sized ones; staging was ~30 % of the kernel's
+    // VALU instructions, most of it address arithmetic and predicates per load.  Chunks may run past a row's end into
+    // the next row / plane of the same arena; those bytes land in LDS columns no window of the tile reads.
     {
         // plane 0: level i, origin (2*X0, 2*Y0), PITCH0 bytes per row
         const uint8_t *p0 = fbase + L0.off[0];
         const int gx0 = 2 * X0, gy0 = 2 * Y0;
-        const int n0 = (2 * th + 22) * (PITCH0 / 4);
-        constexpr int K0 = (ROWS0 * (PITCH0 / 4) + NT - 1) / NT;
-        uint32_t v0[K0];
+        constexpr int C0 = PITCH0 / 16;
+        const int n0 = (2 * th + 22) * C0;
+        constexpr int K0 = (ROWS0 * C0 + NT - 1) / NT;
+        uint4 v0[K0];
 #pragma unroll
         for (int k = 0; k < K0; k++) {
             const int i = (int)tid + k * NT;
-            const int r = i / (PITCH0 / 4), c4 = (i - r * (PITCH0 / 4)) * 4;
-            const int gy = gy0 + r, gx = gx0 + c4;
-            v0[k] = 0;
-            if (i < n0 && gy < L0.h && gx < L0.stride) v0[k] = *reinterpret_cast<const uint32_t *>(p0 + (size_t)gy * L0.stride + gx);
+            const int r = i / C0, c16 = (i - r * C0) * 16;
+            const int gy = gy0 + r, gx = gx0 + c16;
+            v0[k] = make_uint4(0u, 0u, 0u, 0u);
+            if (i < n0 && gy < L0.h && gx < L0.stride) v0[k] = *reinterpret_cast<const uint4 *>(p0 + (size_t)gy * L0.stride + gx);
         }
         // planes 1 + 2: half-step grid cell (X, Y) = { level i+6 pixel (X0+X, Y0+Y),  variant q pixel ((X0+X)>>1, (Y0+Y)>>1) }
         // with q = ((Y0+Y)&1)*2 + ((X0+X)&1)   (ccv.js:132-146: variant q is level i+6 shifted by (dx,dy) then halved).
-        // A thread builds 4 consecutive cells from one dword of level i+6 and one halfword of each of the two variants.
+        // A thread builds 8 consecutive cells from 8 bytes of level i+6 and 4 bytes of each of the two variants.
         const uint8_t *p1 = fbase + L1.off[0];
-        constexpr int GG = (TXH + 11 + 3) / 4;  // cell groups per row (19)
+        constexpr int GG = (TXH + 11 + 7) / 8;  // cell groups per row (10)
         const int n12 = (th + 11) * GG;
         constexpr int K12 = (GH * GG + NT - 1) / NT;
-        uint32_t va[K12], vb[K12], vc[K12];
+        uint2 va[K12];
+        uint32_t vb[K12], vc[K12];
 #pragma unroll
         for (int k = 0; k < K12; k++) {
             const int g = (int)tid + k * NT;
-            const int Y = g / GG, Xg = (g - Y * GG) * 4;
+            const int Y = g / GG, Xg = (g - Y * GG) * 8;
             const int ay = Y0 + Y, ax = X0 + Xg, y2 = ay >> 1, x2 = ax >> 1;
             const uint32_t o2a = (ay & 1) ? L2.off[2] : L2.off[0], o2b = (ay & 1) ? L2.off[3] : L2.off[1];
-            va[k] = vb[k] = vc[k] = 0;
+            va[k] = make_uint2(0u, 0u);
+            vb[k] = vc[k] = 0;
             if (g < n12) {
-                if (ay < L1.h && ax < L1.stride) va[k] = *reinterpret_cast<const uint32_t *>(p1 + (size_t)ay * L1.stride + ax);
+                if (ay < L1.h && ax < L1.stride) va[k] = *reinterpret_cast<const uint2 *>(p1 + (size_t)ay * L1.stride + ax);
                 if (y2 < L2.h && x2 < L2.stride) {
-                    vb[k] = *reinterpret_cast<const uint16_t *>(fbase + o2a + (size_t)y2 * L2.stride + x2);
-                    vc[k] = *reinterpret_cast<const uint16_t *>(fbase + o2b + (size_t)y2 * L2.stride + x2);
+                    vb[k] = *reinterpret_cast<const uint32_t *>(fbase + o2a + (size_t)y2 * L2.stride + x2);
+                    vc[k] = *reinterpret_cast<const uint32_t *>(fbase + o2b + (size_t)y2 * L2.stride + x2);
                 }
             }
         }
 #pragma unroll
         for (int k = 0; k < K0; k++) {
             const int i = (int)tid + k * NT;
-            if (i < n0) *reinterpret_cast<uint32_t *>(&lds[i * 4]) = v0[k];  // rows are contiguous: r*PITCH0 + c4 == i*4
+            if (i < n0) *reinterpret_cast<uint4 *>(&lds[i * 16]) = v0[k];  // rows are contiguous: r*PITCH0 + c16 == i*16
         }
 #pragma unroll
         for (int k = 0; k < K12; k++) {
             const int g = (int)tid + k * NT;
             if (g < n12) {
-                const int Y = g / GG, Xg = (g - Y * GG) * 4;
-                const uint32_t a = va[k], b = vb[k], c = vc[k];
-                uint2 w;
-                w.x = (a & 0xffu) | ((b & 0xffu) << 8) | ((a & 0xff00u) << 8) | ((c & 0xffu) << 24);
-                w.y = ((a >> 16) & 0xffu) | (b & 0xff00u) | ((a >> 8) & 0xff0000u) | ((c & 0xff00u) << 16);
-                *reinterpret_cast<uint2 *>(&lds[P12_BASE + Y * G_PITCH + 2 * Xg]) = w;
+                const int Y = g / GG, Xg = (g - Y * GG) * 8;
+                const uint32_t b = vb[k], c = vc[k];
+                // cell j = { a_j, (j even ? b : c)_{j/2} }: v_perm_b32 picks bytes from {src0 = bytes 4-7, src1 = bytes 0-3}
+                uint4 w;
+                w.x = __builtin_amdgcn_perm(c, __builtin_amdgcn_perm(b, va[k].x, 0x00010400u), 0x04020100u);  // a0 b0 a1 c0
+                w.y = __builtin_amdgcn_perm(c, __builtin_amdgcn_perm(b, va[k].x, 0x00030502u), 0x05020100u);  // a2 b1 a3 c1
+                w.z = __builtin_amdgcn_perm(c, __builtin_amdgcn_perm(b, va[k].y, 0x00010600u), 0x06020100u);  // a4 b2 a5 c2
+                w.w = __builtin_amdgcn_perm(c, __builtin_amdgcn_perm(b, va[k].y, 0x00030702u), 0x07020100u);  // a6 b3 a7 c3
+                *reinterpret_cast<uint4 *>(&lds[P12_BASE + Y * G_PITCH + 2 * Xg]) = w;
             }
         }
     }
@@ -1000,7 +1009,7 @@ ht_status ht_scan_plan_tiles(ht_ctx *c) {
         if (S.qw <= 0 || S.qh <= 0) continue;
         S.ntx = (2 * S.qw + TXH - 1) / TXH;
         S.tw2 = (2 * S.qw + S.ntx - 1) / S.ntx;
-        S.tw2 = (S.tw2 + 3) & ~3;  // multiple of 4 half-steps: every tile row starts on a dword in all three planes
+        S.tw2 = (S.tw2 + 7) & ~7;  // multiple of 8 half-steps: tile rows start on 16 / 8 / 4-byte boundaries of the three planes' rows
         S.nty = (2 * S.qh + TYH - 1) / TYH;
         S.th2 = (2 * S.qh + S.nty - 1) / S.nty;
         S.th2 += S.th2 & 1;

@@ -253,25 +253,27 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 const uint32_t pos = base + u * NT + tid;
                 valid[u] = pos < n_in;
                 id[u] = valid[u] ? pos : 0u;
-                yy[u] = (id[u] * S.div_magic) >> 20;
-                xx[u] = id[u] - yy[u] * (uint32_t)S.tw2;
+                yy[u] = __umul24(id[u], S.div_magic) >> 20;  // 24-bit multiplies: v_mul_lo_u32 is quarter rate (id < 2^11, magic < 2^18)
+                xx[u] = id[u] - __umul24(yy[u], (uint32_t)S.tw2);
                 valid[u] = valid[u] && xx[u] < (uint32_t)tw;
             }
             ht_gen_stage_0_x2(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), lds + (valid[1] ? 2u * (yy[1] * PITCH0 + xx[1]) : 0u), Fv[0], Fv[1]);
+            bool pass[2];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                bool pass = valid[u] && Fv[u] >= HT_GEN_FMIN[0];
+                pass[u] = valid[u] && Fv[u] >= HT_GEN_FMIN[0];
                 if (valid[u] && (Fv[u] == HT_GEN_FTIE[0] || force_exact))  // exact tie: the sequential binary64 sum decides
-                    pass = !(eval_stage_lds(lds, 2u * (yy[u] * PITCH0 + xx[u]), feats + st0.first, st0.count) < st0.threshold);
-                const unsigned long long m = __ballot(pass);
-                if (m) {
-                    const uint32_t cnt = __popcll(m);
-                    const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    uint32_t b0 = 0;
-                    if (lane == 0) b0 = atomicAdd(&s_nout, cnt);
-                    b0 = __shfl(b0, 0, 64);
-                    if (pass) qbuf[cur ^ QX][b0 + pre] = (uint16_t)id[u];
-                }
+                    pass[u] = !(eval_stage_lds(lds, 2u * (yy[u] * PITCH0 + xx[u]), feats + st0.first, st0.count) < st0.threshold);
+            }
+            // one queue reservation per wave for both windows (one LDS atomic round trip instead of two, no ds_bpermute)
+            const unsigned long long m0 = __ballot(pass[0]), m1 = __ballot(pass[1]);
+            if (m0 | m1) {
+                const uint32_t c0 = __popcll(m0), c1 = __popcll(m1);
+                uint32_t b0 = 0;
+                if (lane == 0) b0 = atomicAdd(&s_nout, c0 + c1);
+                b0 = __builtin_amdgcn_readfirstlane(b0);
+                if (pass[0]) qbuf[cur ^ QX][b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = (uint16_t)id[0];
+                if (pass[1]) qbuf[cur ^ QX][b0 + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint16_t)id[1];
             }
         }
         if (tid == 0 && my_stats) atomicAdd(&my_stats[0], (unsigned long long)(uint32_t)(tw * th));
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             const uint32_t npush = min(n_in, room);
             for (uint32_t i = tid; i < npush; i += NT) {
                 const uint32_t id = qbuf[cur][qoff + i];
-                const uint32_t yy = (id * S.div_magic) >> 20, xx = id - yy * (uint32_t)S.tw2;
+                const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
                 const uint32_t ax = (uint32_t)X0 + xx, ay = (uint32_t)Y0 + yy;
                 HtQueueEntry e;
                 e.frame = frame;
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             __syncthreads();
             const bool valid = lane < n_in;
             const uint32_t id = valid ? (uint32_t)qbuf[cur][qoff + lane] : 0u;
-            const uint32_t yy = (id * S.div_magic) >> 20, xx = id - yy * (uint32_t)S.tw2;
+            const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
             const uint32_t B = 2u * (yy * PITCH0 + xx);
             const uint32_t part = ht_gen_stage_slice(s, (int)wv, lds + B);
             if (valid && part) atomicAdd(&s_F[lane], part);
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             uint32_t id = 0;
             if (valid) id = (s == 0) ? pos : (uint32_t)qbuf[cur][qoff + pos];
             if (HT_TILE_INPLACE && s > 0) __syncthreads();  // every entry of this chunk is in a register before survivors overwrite the queue
-            const uint32_t yy = (id * S.div_magic) >> 20, xx = id - yy * (uint32_t)S.tw2;
+            const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
             valid = valid && xx < (uint32_t)tw;
             const uint32_t B = 2u * (yy * PITCH0 + xx);
             double sum = 0.0;
@@ -372,11 +374,11 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 uint32_t b0 = 0;
                 if (!last) {
                     if (lane == 0) b0 = atomicAdd(&s_nout, cnt);
-                    b0 = __shfl(b0, 0, 64);
+                    b0 = __builtin_amdgcn_readfirstlane(b0);
                     if (pass) qbuf[cur ^ QX][b0 + pre] = (uint16_t)id;
                 } else {
                     if (lane == 0) b0 = atomicAdd(&ctr->nhits, cnt);
-                    b0 = __shfl(b0, 0, 64);
+                    b0 = __builtin_amdgcn_readfirstlane(b0);
                     if (pass && b0 + pre < hit_cap) {
                         const uint32_t ax = (uint32_t)X0 + xx, ay = (uint32_t)Y0 + yy;
                         ht_hit h;

@@ -10,7 +10,7 @@
 //
 // Device mapping: one tracker ("stream") per frame of the bound batch; state (model histogram, search window, track
 // object) stays in HBM between calls.  track = (1) k_cs_hist: LDS-privatised 4096-bin histogram per frame chunk,
-// merged with global atomics; (2) k_cs_meanshift: ONE workgroup per stream keeps the 4096-entry weight LUT in LDS
+// written as partial histograms (<= 8 per stream, no global atomics); (2) k_cs_meanshift: ONE workgroup per stream keeps the 4096-entry weight LUT in LDS
 // (binary64, 32 KB) and runs the whole <=10-iteration mean-shift loop: each iteration is a window moment reduction
 // straight from the RGBA pixels through the LUT — the back-projection image of the reference (camshift.js:332-353) is
 // never materialised, it is only observable through debug getters.  Moment sums are binary64 with a fixed
@@ -30,7 +30,16 @@ namespace {
 
 constexpr int CS_NT = 512;          // threads of the mean-shift workgroup
 constexpr int HIST_NT = 256;
-constexpr int HIST_PIX_PER_WG = 16384;
+constexpr int HIST_MAX_CHUNKS = 8;   // partial histograms per stream (at least 16384 pixels each)
+
+// frame -> (pixels per chunk, chunks): chunks of >= 16384 pixels, a multiple of 4 * HIST_NT, at most HIST_MAX_CHUNKS per frame
+inline void hist_chunks(uint32_t npix, uint32_t *chunk_px, uint32_t *nchunks) {
+    uint32_t n = std::min<uint32_t>((npix + 16383u) / 16384u, (uint32_t)HIST_MAX_CHUNKS);
+    n = std::max<uint32_t>(n, 1u);
+    const uint32_t q = 4u * HIST_NT;
+    *chunk_px = std::max<uint32_t>(((npix + n - 1) / n + q - 1) / q * q, q);
+    *nchunks = std::max<uint32_t>((npix + *chunk_px - 1) / *chunk_px, 1u);
+}
 
 __device__ __forceinline__ uint32_t cs_bin(uint32_t px) {  // camshift.js:63-66 (px = R | G<<8 | B<<16 | A<<24)
     return ((px & 0xf0u) << 4) | ((px >> 8) & 0xf0u) | ((px >> 20) & 0xfu);
@@ -70,21 +79,55 @@ __global__ __launch_bounds__(256) void k_cs_init(const uint8_t *__restrict__ fra
     }
 }
 
-// full-frame histogram (camshift.js:268): grid (chunks, streams); hist[stream][4096] zeroed by the host
+// full-frame histogram (camshift.js:268): grid (chunks, streams) -> hist[stream][chunk][4096] partial histograms.
+// 4 pixels per 16-byte load.  LDS atomics on one address serialise lane by lane, and flat image regions put whole
+// wavefronts into one bin (a flat 320x240 background cost 64 cycles per wave instruction: the kernel ran at a quarter of
+// HBM speed), so counts are merged before they reach LDS: the 4 pixels of a thread when they share a bin, and all lanes
+// that share the first active lane's bin through one ballot — one atomic for the whole wavefront on flat regions,
+// a few extra scalar instructions elsewhere.  Counts are integers: any order gives the same histogram.
+__device__ __forceinline__ void hist_add_wave(uint32_t *h, uint32_t bin, uint32_t count, bool active) {
+    const unsigned long long act = __ballot(active);
+    if (!act) return;
+    const uint32_t lead_lane = (uint32_t)__builtin_ctzll(act);
+    const uint32_t lead_bin = (uint32_t)__builtin_amdgcn_readlane((int)bin, (int)lead_lane);
+    const uint32_t lead_cnt = (uint32_t)__builtin_amdgcn_readlane((int)count, (int)lead_lane);
+    const bool same = active && bin == lead_bin && count == lead_cnt;
+    const unsigned long long m = __ballot(same);
+    if ((threadIdx.x & 63u) == lead_lane) atomicAdd(&h[lead_bin], lead_cnt * (uint32_t)__popcll(m));
+    if (active && !same) atomicAdd(&h[bin], count);
+}
+
 __global__ __launch_bounds__(HIST_NT) void k_cs_hist(const uint8_t *__restrict__ frames, size_t frame_stride, uint32_t npix,
-                                                     uint32_t *__restrict__ hist) {
+                                                     uint32_t chunk_px, uint32_t *__restrict__ hist) {
     __shared__ uint32_t h[4096];
     for (int i = threadIdx.x; i < 4096; i += HIST_NT) h[i] = 0;
     __syncthreads();
-    const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)blockIdx.y * frame_stride);
-    const uint32_t beg = blockIdx.x * HIST_PIX_PER_WG, end = min(beg + HIST_PIX_PER_WG, npix);
-    for (uint32_t i = beg + threadIdx.x; i < end; i += HIST_NT) atomicAdd(&h[cs_bin(img[i])], 1u);
-    __syncthreads();
-    uint32_t *out = hist + (size_t)blockIdx.y * 4096;
-    for (int i = threadIdx.x; i < 4096; i += HIST_NT) {
-        const uint32_t v = h[i];
-        if (v) atomicAdd(&out[i], v);
+    const uint8_t *frame = frames + (size_t)blockIdx.y * frame_stride;
+    const uint32_t beg = blockIdx.x * chunk_px, end = min(beg + chunk_px, npix);  // chunk_px is a multiple of 4 * HIST_NT
+    const uint32_t nquad = (end - beg) / 4;
+    const uint4 *img4 = reinterpret_cast<const uint4 *>(frame + (size_t)beg * 4);
+    const uint32_t iters = chunk_px / (4 * HIST_NT);
+#pragma unroll 4
+    for (uint32_t it = 0; it < iters; it++) {
+        const uint32_t i = it * HIST_NT + threadIdx.x;
+        const bool on = i < nquad;
+        uint4 p = make_uint4(0u, 0u, 0u, 0u);
+        if (on) p = img4[i];
+        const uint32_t b0 = cs_bin(p.x), b1 = cs_bin(p.y), b2 = cs_bin(p.z), b3 = cs_bin(p.w);
+        const bool flat = (b0 == b1) && (b2 == b3) && (b0 == b2);
+        hist_add_wave(h, b0, flat ? 4u : 1u, on);
+        if (on && !flat) {
+            atomicAdd(&h[b1], 1u);
+            atomicAdd(&h[b2], 1u);
+            atomicAdd(&h[b3], 1u);
+        }
     }
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(frame);
+    for (uint32_t i = beg + nquad * 4 + threadIdx.x; i < end; i += HIST_NT) atomicAdd(&h[cs_bin(img[i])], 1u);  // < 4 pixels
+    __syncthreads();
+    // this chunk's partial histogram, written whole (no zeroing pass, no global atomics); k_cs_meanshift adds the chunks
+    uint32_t *out = hist + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4096;
+    for (int i = threadIdx.x; i < 4096; i += HIST_NT) out[i] = h[i];
 }
 
 struct Mom {
@@ -138,17 +181,18 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
 }
 
 __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H,
-                                                        const uint32_t *__restrict__ hist, HtCsState *__restrict__ states, int first,
-                                                        int calc_angles, ht_cs_trackobj *__restrict__ out) {
+                                                        const uint32_t *__restrict__ hist, int nchunks, HtCsState *__restrict__ states,
+                                                        int first, int calc_angles, ht_cs_trackobj *__restrict__ out) {
     __shared__ double lut[4096];
     __shared__ double red[6][CS_NT / 64];
     __shared__ int s_sw[4];
     const int s = blockIdx.x;
     HtCsState &st = states[first + s];
-    const uint32_t *cur = hist + (size_t)s * 4096;
+    const uint32_t *cur = hist + (size_t)s * nchunks * 4096;
     const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)s * frame_stride);
     for (int i = threadIdx.x; i < 4096; i += CS_NT) {  // getWeights, camshift.js:314-330
-        const uint32_t ch = cur[i];
+        uint32_t ch = 0;
+        for (int k = 0; k < nchunks; k++) ch += cur[(size_t)k * 4096 + i];  // the frame's histogram = sum of its chunks
         double p = 0.0;
         if (ch != 0) {
             p = (double)st.model[i] / (double)ch;
@@ -239,7 +283,7 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
     c->d_cs_hist = nullptr;
     c->d_cs_out = nullptr;
-    HT_HIP(c, hipMalloc(&c->d_cs_hist, sizeof(uint32_t) * 4096 * (size_t)nstreams));
+    HT_HIP(c, hipMalloc(&c->d_cs_hist, sizeof(uint32_t) * 4096 * HIST_MAX_CHUNKS * (size_t)nstreams));
     HT_HIP(c, hipMalloc(&c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)nstreams));
     c->cs_streams = nstreams;
     return HT_OK;
@@ -268,16 +312,16 @@ extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n
     if (c->W == 0 || c->H == 0) return HT_OK;  // camshift.js:219
     HT_HIP(c, hipSetDevice(c->device));
     const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
-    HT_HIP(c, hipMemsetAsync(c->d_cs_hist, 0, sizeof(uint32_t) * 4096 * (size_t)n, c->stream));
+    uint32_t chunk_px, nchunks;
+    hist_chunks(npix, &chunk_px, &nchunks);
     {
         HtProfScope ps(c, "cs_hist");
-        hipLaunchKernelGGL(k_cs_hist, dim3((npix + HIST_PIX_PER_WG - 1) / HIST_PIX_PER_WG, n), dim3(HIST_NT), 0, c->stream, c->d_frames,
-                           c->frame_stride, npix, c->d_cs_hist);
+        hipLaunchKernelGGL(k_cs_hist, dim3(nchunks, n), dim3(HIST_NT), 0, c->stream, c->d_frames, c->frame_stride, npix, chunk_px, c->d_cs_hist);
         HT_HIP(c, hipGetLastError());
     }
     {
         HtProfScope ps(c, "cs_meanshift");
-        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, c->d_cs_hist, c->d_cs,
+        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, c->d_cs_hist, (int)nchunks, c->d_cs,
                            first, calc_angles, c->d_cs_out);
         HT_HIP(c, hipGetLastError());
     }

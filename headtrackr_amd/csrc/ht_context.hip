@@ -249,6 +249,9 @@ static void free_geometry(ht_ctx *c) {
         if (p) (void)hipFree(p);
     c->d_gen_blocks.clear();
     if (c->d_tile_refs) (void)hipFree(c->d_tile_refs), c->d_tile_refs = nullptr;
+    if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
+    if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;
+    c->tail_first_gen = 0;
     c->h_gens.clear();
     c->gen_blocks.clear();
     c->h_scales.clear();
@@ -439,6 +442,49 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
     if (hipMalloc(&c->d_arena, c->arena_stride * (uint64_t)max_batch) != hipSuccess)
         return ht_fail(c, HT_ERR_NOMEM, "ht_set_geometry: hipMalloc(pyramid arena) failed");
     HT_HIP(c, hipMemset(c->d_arena, 0, c->arena_stride * (uint64_t)max_batch));
+
+    // tail plan: from the first generation g0 on which every generation has <= HT_TAIL_MAX_JOBS jobs and all of them
+    // together <= 32768 destination pixels per frame, one workgroup per frame does the rest of the pyramid in one launch
+    // (k_resample_tail) instead of one nearly empty launch per generation
+    c->tail_first_gen = 0;
+    if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
+    if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;
+    if (!getenv("HT_DEBUG_RS_NOTAIL")) {
+        int g0 = ngen;
+        uint64_t px = 0;
+        for (int g = ngen - 1; g >= 1; g--) {
+            uint64_t gp = 0;
+            for (auto &j : c->h_gens[g]) gp += (uint64_t)j.cw * j.ch;
+            if (c->h_gens[g].size() > (size_t)HT_TAIL_MAX_JOBS || px + gp > 32768) break;
+            px += gp;
+            g0 = g;
+        }
+        if (ngen - g0 >= 2 && ngen - g0 <= HT_TAIL_MAX_GENS) {
+            std::vector<HtResampleJob> tj;
+            std::vector<uint32_t> pref;
+            HtTailGens &T = c->h_tail;
+            std::memset(&T, 0, sizeof(T));
+            T.ngen = ngen - g0;
+            for (int g = g0; g < ngen; g++) {
+                T.job_begin[g - g0] = (int32_t)tj.size();
+                uint32_t groups = 0;
+                for (auto &j : c->h_gens[g]) {
+                    tj.push_back(j);
+                    pref.push_back(groups);
+                    groups += (uint32_t)((j.cw + 3) / 4) * (uint32_t)j.ch;
+                }
+                T.groups[g - g0] = groups;
+            }
+            T.job_begin[T.ngen] = (int32_t)tj.size();
+            if (!tj.empty()) {
+                HT_HIP(c, hipMalloc(&c->d_tail_jobs, tj.size() * sizeof(HtResampleJob)));
+                HT_HIP(c, hipMemcpy(c->d_tail_jobs, tj.data(), tj.size() * sizeof(HtResampleJob), hipMemcpyHostToDevice));
+                HT_HIP(c, hipMalloc(&c->d_tail_prefix, pref.size() * sizeof(uint32_t)));
+                HT_HIP(c, hipMemcpy(c->d_tail_prefix, pref.data(), pref.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                c->tail_first_gen = g0;
+            }
+        }
+    }
 
     ht_status st = ht_scan_plan_tiles(c);
     if (st != HT_OK) return st;

@@ -82,6 +82,15 @@ struct HtDevLevel {
 };
 
 // One resample job = one canvas of the pyramid (ccv.js:121,128,135,140,145).
+// k_resample_tail argument: generations [first, first + ngen) as ranges into the tail job table
+constexpr int HT_TAIL_MAX_GENS = 8;
+constexpr int HT_TAIL_MAX_JOBS = 32;  // per generation (6 levels x 4 variants = 24 in the reference's pyramid)
+struct HtTailGens {
+    int32_t ngen;
+    int32_t job_begin[HT_TAIL_MAX_GENS + 1];
+    uint32_t groups[HT_TAIL_MAX_GENS];  // 4-pixel groups (canvas width rounded up to 4, times canvas height) per generation
+};
+
 // One drawImage call (host job list) and, with the tile fields filled in, one k_resample workgroup (device tile table).
 constexpr int HT_RS_SRC_ROWS = 76;   // k_resample LDS window: source rows per tile
 constexpr int HT_RS_MAX_PASSES = 4;  // k_resample: 16-row passes per tile at most
@@ -187,6 +196,11 @@ struct ht_ctx {
     std::vector<HtScanScale> h_scales;
     HtScanScale *d_scales = nullptr;
     uint32_t tiles_per_frame = 0;
+    // k_resample_tail: the last generations (tiny levels) in ONE launch, one workgroup per frame
+    int tail_first_gen = 0;                  // first generation handled by the tail kernel (0 = none)
+    HtResampleJob *d_tail_jobs = nullptr;    // jobs of generations >= tail_first_gen, generation by generation
+    uint32_t *d_tail_prefix = nullptr;       // per job: 4-pixel groups of the jobs before it in its generation
+    HtTailGens h_tail;                       // per generation: job range and group count (kernel argument)
     int rs_min_wgs = 2048;  // ... but never fewer workgroups per launch than this (HT_DEBUG_RS_MINWG)
     int rs_group = 8;  // k_resample: frames per workgroup at most (HT_DEBUG_RS_GROUP)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)

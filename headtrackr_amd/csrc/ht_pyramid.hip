@@ -317,6 +317,61 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
     }
 }
 
+// The last generations of the pyramid are a few thousand pixels per frame: as k_resample launches they are 3-4 nearly
+// empty grids whose cost is launch + latency chain (C2: 48 us for 6 % of the pixels).  Here ONE workgroup per frame walks
+// those generations in order: a thread produces 4 destination pixels straight from HBM/L2 (own tap evaluation, no LDS
+// staging), generations are separated by a workgroup barrier.  Same arithmetic as k_resample's HBM-tap path.
+constexpr int TAIL_NT = 1024;
+__global__ __launch_bounds__(TAIL_NT) void k_resample_tail(const HtResampleJob *__restrict__ jobs, const uint32_t *__restrict__ prefix,
+                                                          const HtTailGens G, uint8_t *__restrict__ arena, uint64_t arena_stride,
+                                                          uint32_t nframes) {
+    __shared__ HtResampleJob s_jobs[HT_TAIL_MAX_JOBS];
+    __shared__ uint32_t s_pref[HT_TAIL_MAX_JOBS + 1];
+    uint32_t fidx, item;
+    if (!xcd_item(1u, nframes, &fidx, &item)) return;  // same frame -> XCD placement as the generations before
+    uint8_t *frame = arena + (uint64_t)fidx * arena_stride;
+    const int tid = (int)threadIdx.x;
+    for (int g = 0; g < G.ngen; g++) {
+        const int jb = G.job_begin[g], nj = G.job_begin[g + 1] - jb;
+        const uint32_t total = G.groups[g];
+        {
+            const uint32_t *src32 = reinterpret_cast<const uint32_t *>(jobs + jb);
+            uint32_t *dst32 = reinterpret_cast<uint32_t *>(s_jobs);
+            for (int i = tid; i < nj * (int)(sizeof(HtResampleJob) / 4); i += TAIL_NT) dst32[i] = src32[i];
+            if (tid < nj) s_pref[tid] = prefix[jb + tid];
+            if (tid == 0) s_pref[nj] = total;
+        }
+        __syncthreads();
+        for (uint32_t i = (uint32_t)tid; i < total; i += TAIL_NT) {
+            int lo = 0, hi = nj;  // job of this group: last prefix <= i
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_pref[mid] <= i) lo = mid;
+                else hi = mid;
+            }
+            const HtResampleJob &J = s_jobs[lo];
+            const uint32_t q = i - s_pref[lo], qpr = (uint32_t)(J.cw + 3) >> 2;
+            const uint32_t y = q / qpr, x0 = (q - y * qpr) * 4u;
+            uint32_t o = 0;
+            const int npx = min(4, J.dw - (int)x0);
+            if ((int)y < J.dh && npx > 0) {
+                const uint8_t *src = frame + J.src_off;
+                RsTap cx[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) cx[k] = rs_tap(min((int)x0 + k, J.dw - 1), J.rx, J.sw, J.sx);
+                const RsTap ry = rs_tap((int)y, J.ry, J.sh, J.sy);
+                o = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * J.src_stride, src + (size_t)ry.b * J.src_stride, cx, ry, 0, npx);
+            }
+            *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o;  // incl. the transparent border
+        }
+        // the next generation reads what this workgroup just wrote: a workgroup-scope barrier is enough — the stores are
+        // complete in L2 (write-through L1) before the barrier releases, and this CU cannot hold a stale L1 copy of a
+        // destination line (nothing reads a plane before the generation that writes it; planes are 256-byte aligned).
+        // Agent-scope fences here cost 4x the whole kernel: buffer_wbl2 writes the XCD's entire dirty L2 back.
+        __syncthreads();
+    }
+}
+
 // per-frame channel sums for getWhitebalance; out[f*4 + c] (u64), zeroed by the host
 __global__ __launch_bounds__(256) void k_channel_sums(const uint8_t *__restrict__ frames, size_t frame_stride, uint32_t npix,
                                                       unsigned long long *__restrict__ out) {
@@ -370,7 +425,8 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         }
         HT_HIP(c, hipGetLastError());
     }
-    for (size_t g = 1; g < c->h_gens.size(); g++) {
+    const size_t regular_end = c->tail_first_gen > 0 ? (size_t)c->tail_first_gen : c->h_gens.size();
+    for (size_t g = 1; g < regular_end; g++) {
         if (c->gen_blocks[g] == 0) continue;
         HtProfScope ps(c, "resample");
         // frames per workgroup: as many as keep >= ~4 workgroups per CU slot in the launch, at most rs_group; groups never
@@ -383,6 +439,12 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         const dim3 rgrid((c->gen_blocks[g] * ngroups + 7u) & ~7u);
         hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,
                            c->gen_blocks[g], ngroups, (uint32_t)c->nframes, K);
+        HT_HIP(c, hipGetLastError());
+    }
+    if (c->tail_first_gen > 0) {
+        HtProfScope ps(c, "resample");
+        hipLaunchKernelGGL(k_resample_tail, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
+                           c->h_tail, c->d_arena, c->arena_stride, (uint32_t)c->nframes);
         HT_HIP(c, hipGetLastError());
     }
     return HT_OK;

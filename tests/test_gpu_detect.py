@@ -82,8 +82,7 @@ def test_golden_case(ctx, case, cascade):
     assert ctx.whitebalance()[0] == case["whitebalance"]
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (64, 48), (38, 30), (641, 363)])
-def test_pyramid_planes_vs_oracle(ctx, w, h):
+def _check_pyramid(ctx, w, h):
     frames = np.stack([synth.noise_frame(w, h, 3), synth.smooth_frame(w, h, 4), synth.face_frame(w, h, [(w // 8, h // 8, min(w, h) // 2)])])
     ctx.set_geometry(w, h, len(frames))
     ctx.upload(frames)
@@ -99,6 +98,23 @@ def test_pyramid_planes_vs_oracle(ctx, w, h):
                 got = ctx.pyramid_readback(f, i, s)
                 want = ho.plane(levels, arena, i, s)
                 assert got.shape == want.shape and np.array_equal(got, want), f"frame {f} level {i} slot {s}"
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (64, 48), (38, 30), (641, 363)])
+def test_pyramid_planes_vs_oracle(ctx, w, h):
+    _check_pyramid(ctx, w, h)
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (38, 30)])
+def test_pyramid_without_tail_kernel(w, h, monkeypatch):
+    """The last (tiny) generations are built by k_resample_tail by default; with HT_DEBUG_RS_NOTAIL every generation goes
+    through k_resample.  Both must produce the oracle's planes bit for bit."""
+    monkeypatch.setenv("HT_DEBUG_RS_NOTAIL", "1")
+    c = Context()
+    try:
+        _check_pyramid(c, w, h)
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("mode", [0, HT_SCAN_NO_SPLIT, HT_SCAN_SIMPLE, HT_SCAN_GENERIC, HT_SCAN_GENERIC | HT_SCAN_NO_SPLIT],

@@ -16,11 +16,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-short = {"k_gray_linear": "gray", "k_resample": "resample", "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep"}
+short = {"k_gray_linear": "gray", "k_resample": "resample", "k_resample_tail": "resample_tail", "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep"}
 traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/gpu_pmc.sh): bytes = "
            "(2*FETCH_SIZE + WRITE_SIZE)*1024.  On gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section); "
            "calibrated here on k_gray_linear, whose traffic is known exactly (reads W*H*4, writes W*H per frame): see gray_check. "
-           "Averages per launch; k_resample is the mean over its 7 launches per step."}
+           "Averages per launch; k_resample is the mean over its launches per step (one per pyramid generation; the last generations are one k_resample_tail launch)."}
 for wl in ("c2", "c4"):
     ks = glob.glob(os.path.join(G, f"prof_{wl}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:

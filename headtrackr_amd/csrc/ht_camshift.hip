@@ -30,11 +30,11 @@ namespace {
 
 constexpr int CS_NT = 512;          // threads of the mean-shift workgroup
 constexpr int HIST_NT = 256;
-constexpr int HIST_MAX_CHUNKS = 8;   // partial histograms per stream (at least 16384 pixels each)
-
-// frame -> (pixels per chunk, chunks): chunks of >= 16384 pixels, a multiple of 4 * HIST_NT, at most HIST_MAX_CHUNKS per frame
-inline void hist_chunks(uint32_t npix, uint32_t *chunk_px, uint32_t *nchunks) {
-    uint32_t n = std::min<uint32_t>((npix + 16383u) / 16384u, (uint32_t)HIST_MAX_CHUNKS);
+// Partial histograms per stream: enough chunks to put ~1024 workgroups on the chip (a single 1080p stream gets 127, a
+// batch of >= 128 streams 8 each), each chunk >= 16384 pixels and a multiple of 4 * HIST_NT.
+inline uint32_t hist_max_chunks(int nstreams) { return (uint32_t)std::min(128, std::max(8, 1024 / std::max(nstreams, 1))); }
+inline void hist_chunks(uint32_t npix, uint32_t max_chunks, uint32_t *chunk_px, uint32_t *nchunks) {
+    uint32_t n = std::min<uint32_t>((npix + 16383u) / 16384u, max_chunks);
     n = std::max<uint32_t>(n, 1u);
     const uint32_t q = 4u * HIST_NT;
     *chunk_px = std::max<uint32_t>(((npix + n - 1) / n + q - 1) / q * q, q);
@@ -190,15 +190,27 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
     HtCsState &st = states[first + s];
     const uint32_t *cur = hist + (size_t)s * nchunks * 4096;
     const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)s * frame_stride);
-    for (int i = threadIdx.x; i < 4096; i += CS_NT) {  // getWeights, camshift.js:314-330
-        uint32_t ch = 0;
-        for (int k = 0; k < nchunks; k++) ch += cur[(size_t)k * 4096 + i];  // the frame's histogram = sum of its chunks
-        double p = 0.0;
-        if (ch != 0) {
-            p = (double)st.model[i] / (double)ch;
-            p = p < 1.0 ? p : 1.0;
+    {  // getWeights, camshift.js:314-330; the frame's histogram = sum of its chunk histograms (4 bins per 16-byte load)
+        const uint4 *cur4 = reinterpret_cast<const uint4 *>(cur);
+        const uint4 *model4 = reinterpret_cast<const uint4 *>(st.model);
+        for (int i4 = threadIdx.x; i4 < 1024; i4 += CS_NT) {
+            uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+            for (int k = 0; k < nchunks; k++) {
+                const uint4 v = cur4[(size_t)k * 1024 + i4];
+                acc.x += v.x, acc.y += v.y, acc.z += v.z, acc.w += v.w;
+            }
+            const uint4 m = model4[i4];
+            const uint32_t chv[4] = {acc.x, acc.y, acc.z, acc.w}, mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                double p = 0.0;
+                if (chv[q] != 0) {
+                    p = (double)mv[q] / (double)chv[q];
+                    p = p < 1.0 ? p : 1.0;
+                }
+                lut[i4 * 4 + q] = p;
+            }
         }
-        lut[i] = p;
     }
     if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
     __syncthreads();
@@ -283,7 +295,7 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
     c->d_cs_hist = nullptr;
     c->d_cs_out = nullptr;
-    HT_HIP(c, hipMalloc(&c->d_cs_hist, sizeof(uint32_t) * 4096 * HIST_MAX_CHUNKS * (size_t)nstreams));
+    HT_HIP(c, hipMalloc(&c->d_cs_hist, sizeof(uint32_t) * 4096 * hist_max_chunks(nstreams) * (size_t)nstreams));
     HT_HIP(c, hipMalloc(&c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)nstreams));
     c->cs_streams = nstreams;
     return HT_OK;
@@ -313,7 +325,7 @@ extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n
     HT_HIP(c, hipSetDevice(c->device));
     const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
     uint32_t chunk_px, nchunks;
-    hist_chunks(npix, &chunk_px, &nchunks);
+    hist_chunks(npix, hist_max_chunks(c->cs_streams), &chunk_px, &nchunks);  // buffer sized for cs_streams x that many chunks
     {
         HtProfScope ps(c, "cs_hist");
         hipLaunchKernelGGL(k_cs_hist, dim3(nchunks, n), dim3(HIST_NT), 0, c->stream, c->d_frames, c->frame_stride, npix, chunk_px, c->d_cs_hist);

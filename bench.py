@@ -62,32 +62,41 @@ def stream_bench(a, torch, dist, rank, world, local):
     fbytes = W * H * 4
     lat = {"detect": [], "track": []}
 
-    def frame(i):
-        t0 = time.perf_counter()
-        ctx.upload_ptr(host.data_ptr() + (i % nuniq) * fbytes, 1)
+    def process(i):
         if i % 30 == 0:
             ctx.detect_enqueue(0)
             hits, counts = ctx.detect_collect(cap=1 << 14)
             best = ctx.best_faces(hits, counts, 1)[0]
             if best["neighbors"] > 0 and best["confidence"] > -10:
                 ctx.camshift_init([[int(np.floor(best["x"])), int(np.floor(best["y"])), int(np.floor(best["width"])), int(np.floor(best["height"]))]])
-            out = best
-            lat["detect"].append((time.perf_counter() - t0) * 1e3)
-        else:
-            out = ctx.camshift_track(1, calc_angles=True)[0]
-            lat["track"].append((time.perf_counter() - t0) * 1e3)
+            return best
+        return ctx.camshift_track(1, calc_angles=True)[0]
+
+    def frame(i):  # strictly in turn: upload, process, result — the latency of one frame on an idle pipeline
+        t0 = time.perf_counter()
+        ctx.upload_ptr(host.data_ptr() + (i % nuniq) * fbytes, 1)
+        out = process(i)
+        lat["detect" if i % 30 == 0 else "track"].append((time.perf_counter() - t0) * 1e3)
         return out
 
     for i in range(max(a.warmup, 1) * 30 + 1):
         frame(i)
+    steps = a.steps if a.steps != 20 else 300
     lat = {"detect": [], "track": []}
+    for i in range(steps):  # latency pass (not the timed region)
+        frame(i)
+    # timed region: the same frames with double-buffered ingest (ht_upload_frames_async / ht_swap_frames): frame i+1
+    # crosses PCIe on the copy stream while frame i is processed
+    ctx.upload_async_ptr(host.data_ptr(), 1)
+    ctx.swap_frames()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps = a.steps if a.steps != 20 else 300
     for i in range(steps):
-        last = frame(i)
+        ctx.upload_async_ptr(host.data_ptr() + ((i + 1) % nuniq) * fbytes, 1)
+        last = process(i)
+        ctx.swap_frames()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -100,12 +109,13 @@ def stream_bench(a, torch, dist, rank, world, local):
         allv = np.array(lat["detect"] + lat["track"])
         pct = lambda v, q: round(float(np.percentile(np.array(v), q)), 4) if len(v) else None  # noqa: E731
         print(json.dumps({
-            "metric": "frames/sec streaming 1920x1080 feeds (detect every 30th frame, camshift between), end to end incl. PCIe",
+            "metric": "frames/sec streaming 1920x1080 feeds (detect every 30th frame, camshift between), end to end incl. PCIe (double-buffered ingest)",
             "value": round(world * steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
             "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "C5: one 1920x1080 RGBA feed per GPU, host->GPU every frame, detect on frames 0,30,60,... + camshift.track otherwise",
                        "feeds_per_gpu": 1, "width": W, "height": H, "parallelism": f"{world} feed(s), one per GPU, no collective"},
+            "latency_note": "latency_ms: upload + process + result of one frame strictly in turn (separate untimed pass over the same frames)",
             "latency_ms": {"p50": pct(allv, 50), "p99": pct(allv, 99), "detect_p50": pct(lat["detect"], 50), "detect_max": pct(lat["detect"], 100),
                            "track_p50": pct(lat["track"], 50), "track_p99": pct(lat["track"], 99)},
             "last_track": [float(last["x"]), float(last["y"]), float(last["width"]), float(last["height"])],

@@ -92,6 +92,16 @@ class Context:
         self._check(self._lib.ht_upload_frames(self._h, host_ptr, n, frame_stride or self.width * self.height * 4))
         self.nframes = n
 
+    def upload_async_ptr(self, host_ptr: int, n: int, frame_stride: int | None = None):
+        """Starts copying the NEXT n frames from pinned host memory into the back buffer on the copy stream; the kernels of
+        the current frames keep running.  swap_frames() makes them current."""
+        self._check(self._lib.ht_upload_frames_async(self._h, host_ptr, n, frame_stride or self.width * self.height * 4))
+        self._back_n = n
+
+    def swap_frames(self):
+        self._check(self._lib.ht_swap_frames(self._h))
+        self.nframes = self._back_n
+
     def bind_device(self, dev_ptr: int, n: int, frame_stride: int | None = None):
         """Use n RGBA frames already resident in device memory (e.g. a torch cuda tensor's data_ptr())."""
         self._check(self._lib.ht_bind_frames_device(self._h, dev_ptr, n, frame_stride or self.width * self.height * 4))

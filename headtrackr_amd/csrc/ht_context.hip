@@ -268,6 +268,10 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_packed_feats) (void)hipFree(c->d_packed_feats);
     if (c->d_stages) (void)hipFree(c->d_stages);
     if (c->d_frames_own) (void)hipFree(c->d_frames_own);
+    if (c->d_frames_back) (void)hipFree(c->d_frames_back);
+    if (c->ev_copy_done) (void)hipEventDestroy(c->ev_copy_done);
+    if (c->ev_front_free) (void)hipEventDestroy(c->ev_front_free);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->d_hits) (void)hipFree(c->d_hits);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_stats) (void)hipFree(c->d_stats);
@@ -543,6 +547,54 @@ extern "C" ht_status ht_upload_frames(ht_ctx *c, const uint8_t *host_rgba, int32
     c->d_frames = c->d_frames_own;
     c->frame_stride = fbytes;
     c->nframes = n;
+    return HT_OK;
+}
+
+extern "C" ht_status ht_upload_frames_async(ht_ctx *c, const uint8_t *host_rgba, int32_t n, size_t frame_stride) {
+    if (!c) return HT_ERR_INVALID;
+    if (c->W == 0) return ht_fail(c, HT_ERR_STATE, "ht_upload_frames_async: call ht_set_geometry first");
+    const size_t fbytes = (size_t)c->W * c->H * 4;
+    if (!host_rgba || n <= 0 || n > c->max_batch || frame_stride < fbytes)
+        return ht_fail(c, HT_ERR_INVALID, "ht_upload_frames_async: bad frame count or stride");
+    HT_HIP(c, hipSetDevice(c->device));
+    if (!c->copy_stream) {
+        HT_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        HT_HIP(c, hipEventCreateWithFlags(&c->ev_copy_done, hipEventDisableTiming));
+        HT_HIP(c, hipEventCreateWithFlags(&c->ev_front_free, hipEventDisableTiming));
+    }
+    const size_t need = fbytes * (size_t)n;
+    if (c->d_frames_back_bytes < need) {
+        HT_HIP(c, hipStreamSynchronize(c->copy_stream));
+        if (c->d_frames_back) (void)hipFree(c->d_frames_back);
+        c->d_frames_back = nullptr;
+        c->d_frames_back_bytes = 0;
+        if (hipMalloc(&c->d_frames_back, need) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "ht_upload_frames_async: hipMalloc failed");
+        c->d_frames_back_bytes = need;
+    }
+    // the back buffer was the front buffer until the last swap: kernels enqueued before that swap may still read it
+    HT_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_front_free, 0));
+    if (frame_stride == fbytes) {
+        HT_HIP(c, hipMemcpyAsync(c->d_frames_back, host_rgba, need, hipMemcpyHostToDevice, c->copy_stream));
+    } else {
+        HT_HIP(c, hipMemcpy2DAsync(c->d_frames_back, fbytes, host_rgba, frame_stride, fbytes, (size_t)n, hipMemcpyHostToDevice, c->copy_stream));
+    }
+    HT_HIP(c, hipEventRecord(c->ev_copy_done, c->copy_stream));
+    c->back_n = n;
+    return HT_OK;
+}
+
+extern "C" ht_status ht_swap_frames(ht_ctx *c) {
+    if (!c) return HT_ERR_INVALID;
+    if (c->back_n <= 0) return ht_fail(c, HT_ERR_STATE, "ht_swap_frames: no ht_upload_frames_async pending");
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipEventRecord(c->ev_front_free, c->stream));            // everything enqueued so far used the old front buffer
+    HT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_copy_done, 0));      // later kernels wait for the copy, the host does not
+    std::swap(c->d_frames_own, c->d_frames_back);
+    std::swap(c->d_frames_own_bytes, c->d_frames_back_bytes);
+    c->d_frames = c->d_frames_own;
+    c->frame_stride = (size_t)c->W * c->H * 4;
+    c->nframes = c->back_n;
+    c->back_n = 0;
     return HT_OK;
 }
 

@@ -208,6 +208,11 @@ struct ht_ctx {
     // frames
     uint8_t *d_frames_own = nullptr;
     size_t d_frames_own_bytes = 0;
+    uint8_t *d_frames_back = nullptr;  // ht_upload_frames_async target; ht_swap_frames exchanges it with d_frames_own
+    size_t d_frames_back_bytes = 0;
+    int back_n = 0;                    // frames in the back buffer (0 = nothing pending)
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy_done = nullptr, ev_front_free = nullptr;
     const uint8_t *d_frames = nullptr;
     size_t frame_stride = 0;
     int nframes = 0;

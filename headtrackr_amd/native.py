@@ -58,7 +58,7 @@ class PlaneInfo(C.Structure):
 # every symbol include/headtrackr_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "ht_create", "ht_destroy", "ht_last_error", "ht_abi_version", "ht_set_geometry", "ht_num_levels", "ht_plane",
-    "ht_windows_per_frame", "ht_pyramid_bytes_per_frame", "ht_upload_frames", "ht_bind_frames_device", "ht_detect_enqueue",
+    "ht_windows_per_frame", "ht_pyramid_bytes_per_frame", "ht_upload_frames", "ht_upload_frames_async", "ht_swap_frames", "ht_bind_frames_device", "ht_detect_enqueue",
     "ht_detect_collect", "ht_detect_batch", "ht_pyramid_readback", "ht_stage_counts", "ht_grayscale_batch",
     "ht_whitebalance_batch", "ht_hits_to_rects", "ht_group_rects", "ht_best_faces", "ht_camshift_reserve", "ht_camshift_init_batch",
     "ht_camshift_track_batch", "ht_allgather_records", "ht_profile", "ht_kernel_times", "ht_stream", "ht_synchronize",
@@ -95,6 +95,10 @@ def lib():
     L.ht_pyramid_bytes_per_frame.argtypes = [vp]
     L.ht_upload_frames.restype = i32
     L.ht_upload_frames.argtypes = [vp, u8p, i32, sz]
+    L.ht_upload_frames_async.restype = i32
+    L.ht_upload_frames_async.argtypes = [vp, u8p, i32, sz]
+    L.ht_swap_frames.restype = i32
+    L.ht_swap_frames.argtypes = [vp]
     L.ht_bind_frames_device.restype = i32
     L.ht_bind_frames_device.argtypes = [vp, vp, i32, sz]
     L.ht_detect_enqueue.restype = i32

@@ -125,6 +125,12 @@ uint64_t ht_pyramid_bytes_per_frame(const ht_ctx *ctx); /* sum of w*h over all p
 
 /* Copies n RGBA frames (frame_stride bytes apart, rows packed) from host memory into the ctx's device buffer. */
 ht_status ht_upload_frames(ht_ctx *ctx, const uint8_t *host_rgba, int32_t n, size_t frame_stride);
+/* Double-buffered ingest for live feeds (the reference's per-frame video -> canvas copy, main.js:170):
+ * ht_upload_frames_async copies the NEXT frames from pinned host memory into the ctx's back buffer on a separate copy
+ * stream, so the copy overlaps the kernels working on the current frames; ht_swap_frames makes the back buffer current
+ * (the compute stream waits for the copy, no host synchronisation).  host_rgba must stay valid until the swap. */
+ht_status ht_upload_frames_async(ht_ctx *ctx, const uint8_t *host_rgba, int32_t n, size_t frame_stride);
+ht_status ht_swap_frames(ht_ctx *ctx);
 /* Uses frames already resident in device memory (no copy; must stay valid until the results were collected). */
 ht_status ht_bind_frames_device(ht_ctx *ctx, const void *dev_rgba, int32_t n, size_t frame_stride);
 

@@ -220,3 +220,29 @@ def test_exact_tie_fallback_path(ctx, cascade, deep_v, monkeypatch):
     assert len(want) > 20 and got.tobytes() == want.tobytes()
     ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(6)])
     assert_hits_equal(got, ref)
+
+
+def test_async_upload_and_swap(cascade):
+    """ht_upload_frames_async + ht_swap_frames (double-buffered ingest): the copy of the next batch runs on the copy stream
+    while the current batch is scanned; results must equal plain uploads, also after several ping-pong swaps."""
+    A = np.ascontiguousarray(synth.mixed_batch(4, 320, 240, seed0=1234))
+    B = np.ascontiguousarray(synth.mixed_batch(4, 320, 240, seed0=4321))
+    c = Context()
+    try:
+        c.set_geometry(320, 240, 4)
+        want_a, _ = c.detect_raw(A)
+        want_b, _ = c.detect_raw(B)
+        assert len(want_a) > 0 and want_a.tobytes() != want_b.tobytes()
+        c.upload(A)
+        for k in range(4):
+            nxt, cur_want = (B, want_a) if k % 2 == 0 else (A, want_b)
+            c.upload_async_ptr(nxt.ctypes.data, 4)   # next batch on the copy stream ...
+            c.detect_enqueue(HT_INPUT_RGBA)         # ... while the current one is scanned
+            got, _ = c.detect_collect()
+            assert got.tobytes() == cur_want.tobytes(), k
+            c.swap_frames()
+        c.detect_enqueue(HT_INPUT_RGBA)
+        got, _ = c.detect_collect()
+        assert got.tobytes() == want_a.tobytes()
+    finally:
+        c.close()

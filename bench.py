@@ -31,15 +31,21 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 1000 for c2, 300 for c4 / c5, 20 for c3: ~0.3-0.5 s of GPU time)")
+    ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default: a tenth of --steps, at least 3)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: 256 for c2/c3, 128 for c4)")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn")
-    return ap.parse_args()
+    ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steady-state work before the warm-up steps (0 for profiler runs)")
+    a = ap.parse_args()
+    if a.steps <= 0:
+        a.steps = {"c2": 1000, "c4": 300, "c3": 20, "c5": 300}[a.workload]
+    if a.warmup < 0:
+        a.warmup = max(3, a.steps // 10) if a.workload != "c5" else 1
+    return a
 
 
 def stream_bench(a, torch, dist, rank, world, local):
@@ -81,7 +87,7 @@ def stream_bench(a, torch, dist, rank, world, local):
 
     for i in range(max(a.warmup, 1) * 30 + 1):
         frame(i)
-    steps = a.steps if a.steps != 20 else 300
+    steps = a.steps
     lat = {"detect": [], "track": []}
     for i in range(steps):  # latency pass (not the timed region)
         frame(i)
@@ -235,6 +241,13 @@ def main():
             hd.allgather_records(rec_local, world, nf)
         return hits, counts
 
+    # setup, before the W warm-up steps: ~0.2 s of the same work so that clocks, the allocator and the page tables are in
+    # their steady state whatever W the caller chose (a 3-step warm-up is 1 ms of GPU time; a cold first run measured
+    # up to 10 % slower)
+    if a.workload != "c3" and a.prewarm > 0:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < a.prewarm:
+            run_steps(8 * depth)
     if a.workload == "c3":
         for _ in range(a.warmup):
             hits, counts = step()

@@ -144,15 +144,12 @@ __device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap (&cx)
 // sum (x * 0 = +0 for every byte x).  The four taps of a pixel are therefore p[0], p[1], p[pitch], p[pitch + 1] from one
 // address (ds_read_u8 with immediate offsets) whatever the clamping; s_src carries one spare row for the p[pitch] read
 // of the last staged row.  Store: round half to even via the 2^52 + 2^51 add (values are within [0, 255]).
-#ifndef HT_RS_BRANCHFREE
-#define HT_RS_BRANCHFREE 0
-#endif
 __device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int (&ia)[4], const double (&cu)[4], const double (&ct)[4],
                                                    double ru, double rt, int npx) {
     uint32_t o = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        if (HT_RS_BRANCHFREE || k < npx) {
+        if (k < npx) {
             const uint8_t *p = row + ia[k];
             const double top = __dadd_rn(__dmul_rn((double)p[0], cu[k]), __dmul_rn((double)p[1], ct[k]));
             const double bot = __dadd_rn(__dmul_rn((double)p[RS_SP], cu[k]), __dmul_rn((double)p[RS_SP + 1], ct[k]));
@@ -160,7 +157,6 @@ __device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int
             o |= (uint32_t)__double2loint(__dadd_rn(vv, 6755399441055744.0)) << (8 * k);
         }
     }
-    if (HT_RS_BRANCHFREE) o &= npx >= 4 ? 0xffffffffu : ((1u << (8 * max(npx, 0))) - 1u);
     return o;
 }
 

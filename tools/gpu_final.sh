@@ -8,13 +8,12 @@ export TMPDIR=/tmp
 echo "== pytest gpu"; timeout 900 python -m pytest tests -m gpu -q --no-header -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest exit $?"; tail -3 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 for wl in c2 c4 c3 c5; do
-  ST=20; W=3; [ $wl = c4 ] && ST=8; [ $wl = c3 ] && ST=3 && W=1; [ $wl = c5 ] && ST=300 && W=1
-  timeout 600 python bench.py --workload $wl --steps $ST --warmup $W > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; echo "bench $wl exit $?"; cut -c1-420 $OUT/bench_$wl.json
+  timeout 600 python bench.py --workload $wl > $OUT/bench_$wl.json 2> $OUT/bench_$wl.err; echo "bench $wl exit $?"; cut -c1-420 $OUT/bench_$wl.json
 done
 timeout 300 python bench.py --workload c2 --pipeline 1 --cpu-seconds 0 > $OUT/bench_c2_p1.json 2>/dev/null
 cd /tmp
 for wl in c2 c4; do
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_$wl -o $wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 8 --warmup 2 --cpu-seconds 0 --pipeline 1 > $GRAFT_REPO_ROOT/$OUT/prof_$wl.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_$wl -o $wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps 8 --warmup 2 --cpu-seconds 0 --prewarm 0 --pipeline 1 > $GRAFT_REPO_ROOT/$OUT/prof_$wl.log 2>&1
 done
 cd $GRAFT_REPO_ROOT
 find $OUT -name "*kernel_trace.csv" -size +1M -delete

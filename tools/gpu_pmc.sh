@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for set in "${@:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY}"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_${WL}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --cpu-seconds 0 > $OUT/pmc_${WL}_$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_${WL}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --cpu-seconds 0 --prewarm 0 > $OUT/pmc_${WL}_$i.log 2>&1
   echo "set $i: $set -> exit $?"
   python - <<PY
 import csv,glob,collections

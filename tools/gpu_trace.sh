@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-launch kernel durations of one bench step (rocprofv3 kernel trace), to see the launch structure of the pyramid
 export TMPDIR=/tmp; WL=${1:-c2}
-cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --cpu-seconds 0 --pipeline 1 > /dev/null 2>&1
+cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -o t -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --cpu-seconds 0 --prewarm 0 --pipeline 1 > /dev/null 2>&1
 python - <<PY
 import csv,glob,re
 f=glob.glob('/tmp/tr/**/t_kernel_trace.csv',recursive=True)[0]

@@ -105,6 +105,40 @@ def test_batch_of_streams_vs_oracle(ctx):
     assert sum(stats) >= 0.95 * len(stats), f"only {sum(stats)}/{len(stats)} track() calls matched the oracle exactly"
 
 
+@pytest.mark.parametrize("w,h,n", [(1920, 1080, 1), (641, 363, 3), (61, 45, 2)], ids=["1080p-1stream", "odd-641x363", "tiny-61x45"])
+def test_frame_sizes_and_chunking(w, h, n):
+    """The histogram pass cuts a frame into chunk histograms (127 for one 1080p stream, 1 for a tiny frame) and handles
+    pixel counts that are not multiples of 4; the mean-shift kernel adds the chunks.  Same answers as the oracle."""
+    steps = 4
+    a, b = max(3, w // 5), max(2, h // 9)  # elongated: a well-conditioned orientation
+    seqs, rects = [], []
+    for s in range(n):
+        cx, cy = w // 2 + 3 * s, h // 2 - 2 * s
+        seqs.append([synth.blob_frame(w, h, cx + k, cy + k // 2, a, b, (4, 3, 5), (200, 60, 40), seed=77 + 13 * s + k) for k in range(steps)])
+        rects.append((cx - a, cy - b, 2 * a, 2 * b))
+    c = Context()
+    try:
+        c.set_geometry(w, h, n)
+        c.camshift_reserve(n)
+        c.upload(np.stack([seqs[s][0] for s in range(n)]))
+        c.camshift_init(rects)
+        oracles = []
+        for s in range(n):
+            o = ho.Camshift(True)
+            o.init_tracker(seqs[s][0], rects[s])
+            oracles.append(o)
+        stats = []
+        for k in range(1, steps):
+            c.upload(np.stack([seqs[s][k] for s in range(n)]))
+            got = c.camshift_track(n, calc_angles=True)
+            for s in range(n):
+                sw, to = oracles[s].track(seqs[s][k])
+                check(got[s], sw, to, stats)
+        assert sum(stats) >= 0.9 * len(stats), f"only {sum(stats)}/{len(stats)} track() calls matched the oracle exactly"
+    finally:
+        c.close()
+
+
 def test_detect_then_track_like_facetrackr(ctx, golden_facetrackr):
     """facetrackr's VJ -> CS hand-over (facetrackr.js:97-108,185-217) driven from Python: detect, floor the best rect,
     initTracker on the COLOUR frame, then track — against the reference-JS state-machine vector"""

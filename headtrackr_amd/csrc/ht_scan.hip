@@ -345,6 +345,41 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 if (pass) qbuf[cur ^ QX][pre] = (uint16_t)id;
                 if (lane == 0) s_nout = (uint32_t)__popcll(m);
             }
+        } else if (GEN && s == 1 && n_in > (uint32_t)NT) {
+            // stage 1 typically still has ~1.7 survivors per thread: two windows per thread per pass like stage 0 (twice
+            // the LDS reads in flight per wait, half the passes, barriers and queue reservations)
+            for (uint32_t base = 0; base < n_in; base += 2 * NT) {
+                uint32_t id[2], Bv[2], Fv[2];
+                bool valid[2], pass[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t pos = base + u * NT + tid;
+                    valid[u] = pos < n_in;
+                    id[u] = valid[u] ? (uint32_t)qbuf[cur][qoff + pos] : 0u;
+                }
+                if (HT_TILE_INPLACE) __syncthreads();  // both entries are in registers before survivors overwrite the queue
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t yy = __umul24(id[u], S.div_magic) >> 20, xx = id[u] - __umul24(yy, (uint32_t)S.tw2);
+                    Bv[u] = 2u * (yy * PITCH0 + xx);
+                }
+                ht_gen_stage_1_x2(lds + (valid[0] ? Bv[0] : 0u), lds + (valid[1] ? Bv[1] : 0u), Fv[0], Fv[1]);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    pass[u] = valid[u] && Fv[u] >= HT_GEN_FMIN[1];
+                    if (valid[u] && (Fv[u] == HT_GEN_FTIE[1] || force_exact))  // exact tie: the sequential binary64 sum decides
+                        pass[u] = !(eval_stage_lds(lds, Bv[u], F, st.count) < st.threshold);
+                }
+                const unsigned long long m0 = __ballot(pass[0]), m1 = __ballot(pass[1]);
+                if (m0 | m1) {
+                    const uint32_t c0 = __popcll(m0), c1 = __popcll(m1);
+                    uint32_t b0 = 0;
+                    if (lane == 0) b0 = atomicAdd(&s_nout, c0 + c1);
+                    b0 = __builtin_amdgcn_readfirstlane(b0);
+                    if (pass[0]) qbuf[cur ^ QX][b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = (uint16_t)id[0];
+                    if (pass[1]) qbuf[cur ^ QX][b0 + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint16_t)id[1];
+                }
+            }
         } else
         for (uint32_t base = 0; base < n_in; base += NT) {
             const uint32_t pos = base + tid;

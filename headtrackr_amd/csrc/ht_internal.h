@@ -201,6 +201,7 @@ struct ht_ctx {
     HtResampleJob *d_tail_jobs = nullptr;    // jobs of generations >= tail_first_gen, generation by generation
     uint32_t *d_tail_prefix = nullptr;       // per job: 4-pixel groups of the jobs before it in its generation
     HtTailGens h_tail;                       // per generation: job range and group count (kernel argument)
+    bool deep_attr_set = false;              // k_scan_deep_lds: > 64 KB dynamic LDS enabled on this context's device
     int rs_min_wgs = 2048;  // ... but never fewer workgroups per launch than this (HT_DEBUG_RS_MINWG)
     int rs_group = 8;  // k_resample: frames per workgroup at most (HT_DEBUG_RS_GROUP)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)

@@ -1117,10 +1117,9 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
         const int deep_v = dv ? atoi(dv) : 4;
         if (deep_v == 4 && c->packed_count && c->h_stages[split].first >= c->packed_first) {
             const size_t lds = (size_t)c->packed_count * sizeof(HtPackedFeature) + 64 * sizeof(HtDevStage) + (size_t)DEEPL_WAVES * (PATCH_BYTES + 512);
-            static bool attr_set = false;
-            if (!attr_set) {
+            if (!c->deep_attr_set) {  // per context (= per device): a single-process multi-GPU host has one context per GPU
                 HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_deep_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                attr_set = true;
+                c->deep_attr_set = true;
             }
             hipLaunchKernelGGL(k_scan_deep_lds, dim3(getenv("HT_DEBUG_DEEP_GRID") ? atoi(getenv("HT_DEBUG_DEEP_GRID")) : 512), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                                c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, force_exact, c->d_queue, c->queue_capacity,

@@ -49,3 +49,16 @@ def test_create_without_gpu_fails_loudly(built_lib):
     with pytest.raises(HtError) as e:
         Context()
     assert "no CPU fallback" in str(e.value) or "no HIP device" in str(e.value)
+
+
+def test_generated_cascade_code_is_in_sync(tmp_path):
+    """headtrackr_amd/csrc/ht_cascade_gen.inc is generated from data/cascade.bin by tools/gen_cascade_code.py (default
+    arguments: 8 stages, 28 loads per group); a stale copy would silently fall back to the table-driven kernels because
+    of its FNV guard — or worse, encode other thresholds.  Regenerate and compare."""
+    import subprocess
+    import sys
+
+    out = tmp_path / "gen.inc"
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_cascade_code.py"), "8", "28", str(out)], stdout=subprocess.DEVNULL)
+    want = open(os.path.join(ROOT, "headtrackr_amd", "csrc", "ht_cascade_gen.inc")).read()
+    assert out.read_text() == want

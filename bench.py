@@ -1,23 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the detect(+camshift) hot path on N MI355X, one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--scaling weak|strong] [--no-sub]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
-gray -> 39-level pyramid -> full BBF cascade scan -> raw hits copied back and sorted (ht_detect_enqueue +
-ht_detect_collect), plus, for N > 1, one RCCL all-gather of the fixed-size per-frame best-face records.
-Workloads (BASELINE.json configs): c2 = 256 x 320x240 detect on every GPU (default; the configuration the metric is
-quoted on), c4 = 128 x 1280x720 per GPU detect (1024 frames on 8 GPUs), c3 = c2's frames, detect once + 60 camshift
-track() calls per step.  Weak scaling: per-GPU work is fixed, value = all ranks' frames / max-over-ranks time.
+gray -> 39-level pyramid -> full BBF cascade scan -> raw hits copied back, sorted, converted to rects, grouped and reduced
+to the best face per frame (ht_detect_enqueue + ht_detect_collect + ht_best_faces = ccv.detect_objects(..., 5, 1) +
+facetrackr's selection, /root/reference/src/ccv.js:109-333, facetrackr.js:147-175), plus, for N > 1, one RCCL all-gather of
+the fixed-size per-frame best-face rectangles.
 
-Extra objects on the line: "roofline" (dominant kernel, HBM bound, live HIP-event timing through the C ABI's
-profiling scopes on the same stream) and "cpu_baseline" (the CPU oracle port, 1 core, bounded sample).
+Workloads (BASELINE.json configs):
+  c2  256 x 320x240 detect per GPU — the headline `value` (the configuration the metric is quoted on);
+  c4  1280x720 detect, 128 frames per GPU (weak) or 1024 frames in total (--scaling strong: 1024 / N per GPU);
+  c3  256 streams of 320x240: detect once + initTracker + 60 camshift track() calls per step (ht_camshift_track_sequence);
+  c5  one live 1920x1080 feed per GPU, PCIe every frame.
+The default run (c2) also measures c4 (weak + strong) and c3 with their own bounded budgets and reports them as
+sub-records of the same JSON line ("sub": {"c4_1gpu", "c4_strong", "c3"}), each with its own `roofline` and, at N = 1, the
+unmodified reference JS timed on the host cores as `cpu_baseline`.  --no-sub skips them (profiler runs).
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -26,6 +34,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+DEFAULT_STEPS = {"c2": 1000, "c4": 300, "c3": 20, "c5": 300}
+SUB_STEPS = {"c4": 100, "c4_strong": 24, "c3": 12}
+GEOM = {"c2": (320, 240, 256), "c3": (320, 240, 256), "c4": (1280, 720, 128)}
+WORKLOAD_TEXT = {
+    "c2": "C2: 256 x 320x240 RGBA frames per GPU, full BBF cascade detect (interval 5) incl. grouping + best face per frame on the host",
+    "c3": "C3: 256 streams of 320x240 per GPU (one moving face each): detect once, initTracker, then 60 camshift track() calls; every processed frame counts",
+    "c4": "C4: 1280x720 frames, full cascade detect incl. grouping + best face per frame, all-gather of best-face rects for N > 1",
+}
 
 
 def parse():
@@ -34,25 +50,397 @@ def parse():
     ap.add_argument("--steps", type=int, default=0, help="timed steps (default: 1000 for c2, 300 for c4 / c5, 20 for c3: ~0.3-0.5 s of GPU time)")
     ap.add_argument("--warmup", type=int, default=-1, help="untimed warm-up steps (default: a tenth of --steps, at least 3)")
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="strong: total frames fixed at 8 x the per-GPU default (c4: 1024) and split over the ranks")
     ap.add_argument("--frames", type=int, default=0, help="frames per GPU (default: 256 for c2/c3, 128 for c4)")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames generated (tiled to --frames)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
     ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn")
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steady-state work before the warm-up steps (0 for profiler runs)")
+    ap.add_argument("--no-sub", action="store_true", help="only the primary workload (no c4 / c3 sub-records)")
     a = ap.parse_args()
     if a.steps <= 0:
-        a.steps = {"c2": 1000, "c4": 300, "c3": 20, "c5": 300}[a.workload]
+        a.steps = DEFAULT_STEPS[a.workload]
     if a.warmup < 0:
         a.warmup = max(3, a.steps // 10) if a.workload != "c5" else 1
     return a
 
 
-def stream_bench(a, torch, dist, rank, world, local):
+class Env:
+    def __init__(self, torch, dist, rank, world, local):
+        self.torch, self.dist, self.rank, self.world, self.local = torch, dist, rank, world, local
+
+    def fence(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt):
+        if self.world > 1:
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device="cuda")
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baselines (rank 0, N = 1 only): bounded samples of the same frames on the box's host cores
+#  * "reference": the UNMODIFIED reference JS, single-threaded Node (its own execution model), from oracle/_ref
+#  * "port":      the plain-C oracle restatement, 1 thread
+
+
+def cpu_detect_baseline(frames, W, H, blob, seconds):
+    from oracle import ht_oracle as ho
+
+    nf = len(frames)
+    ho.detect_raw(frames[0], blob)  # warm
+    t0 = time.perf_counter()
+    done = 0
+    while done < nf and (done < 2 or time.perf_counter() - t0 < seconds / 2):
+        ho.detect_raw(frames[done], blob)
+        done += 1
+    cdt = time.perf_counter() - t0
+    port = dict(value=round(done / cdt, 3), unit="frames/s", cores=1, kind="port",
+                sample=f"first {done} of the {nf} {W}x{H} frames of this workload, oracle/ht_oracle.c detect (gray+pyramid+scan), 1 thread",
+                host_cpus=os.cpu_count())
+    cpu = port
+    gz = os.path.join(ROOT, "oracle", "_ref", "headtrackr_ref.js.gz")
+    node = shutil.which("node")
+    if node and os.path.exists(gz):
+        try:
+            ns = min(nf, 64)
+            with tempfile.NamedTemporaryFile(suffix=".raw") as tf:
+                np.ascontiguousarray(frames[:ns]).tofile(tf.name)
+                r = subprocess.run([node, os.path.join(ROOT, "oracle", "ref_bench.js"), tf.name, str(ns), str(W), str(H), str(seconds)],
+                                   capture_output=True, text=True, timeout=seconds * 6 + 120)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            cpu = dict(value=round(j["fps"], 3), unit="frames/s", cores=1, kind="reference",
+                       sample=f"first {j['frames']} of the {nf} {W}x{H} frames of this workload: unmodified reference JS (ccv.grayscale + ccv.detect_objects(..., 5, 1)) "
+                              f"on oracle/canvas_shim.js, {j['node']} single thread, median {j['ms_median']:.1f} ms/frame, {100 * j['shim_fraction']:.0f}% of it inside the canvas shim",
+                       host_cpus=j["cpus"], cpu_model=j["cpu_model"])
+        except Exception as e:  # the port baseline stands in
+            cpu = dict(port, note=f"reference JS baseline unavailable: {e}")
+    return cpu, port
+
+
+def cpu_camshift_baseline(versions, rect, W, H, seconds):
+    """camshift.Tracker.initTracker + track() (camshift.js:198-312) of ONE stream on its moving frames: the unmodified
+    reference JS (kind "reference") or, without Node / the bundle, the C port."""
+    gz = os.path.join(ROOT, "oracle", "_ref", "headtrackr_ref.js.gz")
+    node = shutil.which("node")
+    nv = len(versions)
+    if node and os.path.exists(gz):
+        try:
+            with tempfile.NamedTemporaryFile(suffix=".raw") as tf:
+                np.ascontiguousarray(versions).tofile(tf.name)
+                r = subprocess.run([node, os.path.join(ROOT, "oracle", "ref_bench.js"), tf.name, str(nv), str(W), str(H), str(seconds), "camshift"] + [str(int(v)) for v in rect],
+                                   capture_output=True, text=True, timeout=seconds * 6 + 120)
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            return dict(value=round(j["fps"], 3), unit="track() calls/s", cores=1, kind="reference",
+                        sample=f"{j['calls']} camshift.Tracker.track() calls of one {W}x{H} stream (initTracker on rect {list(map(int, rect))}, its {nv} moving frames in turn): unmodified reference JS on "
+                               f"oracle/canvas_shim.js, {j['node']} single thread, median {j['ms_median']:.2f} ms/call",
+                        host_cpus=j["cpus"], cpu_model=j["cpu_model"])
+        except Exception as e:
+            note = f"reference JS baseline unavailable: {e}"
+    else:
+        note = "node or oracle/_ref missing"
+    from oracle import ht_oracle as ho
+
+    st = ho.cs_init(versions[0], *[int(v) for v in rect], calc_angles=True)
+    t0 = time.perf_counter()
+    calls = 0
+    while calls < 8 or time.perf_counter() - t0 < seconds / 2:
+        ho.cs_track(st, versions[(calls + 1) % nv])
+        calls += 1
+    return dict(value=round(calls / (time.perf_counter() - t0), 3), unit="track() calls/s", cores=1, kind="port",
+                sample=f"{calls} track() calls of one {W}x{H} stream, oracle/ht_oracle.c, 1 thread", host_cpus=os.cpu_count(), note=note)
+
+
+def device_copy_ceiling(torch):
+    """what a kernel that only reads and writes HBM reaches on this box, measured in the same run."""
+    buf = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(buf)
+    dst.copy_(buf)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(8):
+        dst.copy_(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    gbs = 2.0 * buf.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del buf, dst
+    return gbs
+
+
+def load_traffic(workload):
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tf)).get(workload, {})
+    except Exception:
+        return {}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# detect workloads (c2, c4)
+
+
+def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, cpu_seconds=0.0, prewarm=0.0, full=True):
+    """One detect workload: K timed steps (barrier + synchronize on both sides, max over ranks), then — on rank 0 — the live
+    HIP-event roofline of the dominant kernel and the CPU baseline.  Returns the record (rank 0) or None."""
+    torch, dist, rank, world, local = env.torch, env.dist, env.rank, env.world, env.local
+    from headtrackr_amd import distributed as hd
+    from headtrackr_amd import synth
+    from headtrackr_amd.api import Context
+
+    W, H, nf_default = GEOM[name]
+    if scaling == "strong":  # fixed total = 8 x the per-GPU default (C4: the 1024 frames of BASELINE.json configs[3]), block-sharded
+        total = 8 * nf_default
+        f0, f1 = hd.shard_range(total, rank, world)
+        nf = f1 - f0
+    else:
+        nf = frames_per_gpu or nf_default
+        total = nf * world
+        f0 = rank * nf
+    nf_max = -(-total // world)
+    uniq = min(a.unique or (12 if name == "c4" else 256), nf)
+    # frame g of the job is synthetic frame g mod uniq' of the N/S/F mix (SURVEY.md §8d), seeded per rank
+    base = synth.mixed_batch(uniq, W, H, seed0=1234 + 1000 * rank)
+    dev_uniq = torch.from_numpy(base).cuda()
+    idx = torch.arange(nf, device="cuda") % uniq
+    dev = dev_uniq[idx].contiguous() if nf != uniq else dev_uniq  # resident in HBM before the timed region
+    del dev_uniq
+    depth = max(1, a.pipeline)
+    ctxs = []
+    for _ in range(depth):
+        cx = Context(device=local)
+        cx.set_geometry(W, H, nf)
+        cx.bind_device(dev.data_ptr(), nf, W * H * 4)
+        ctxs.append(cx)
+    ctx = ctxs[0]
+    rec_local = torch.zeros((nf_max, hd.RECORD_F64), dtype=torch.float64, device="cuda")
+    state = {}
+
+    def finish(cx):
+        # raw hits -> seq rects -> ccv's grouping -> facetrackr's best face per frame: all inside the timed step
+        hits, counts = cx.detect_collect(cap=1 << 17)
+        best = cx.best_faces(hits, counts, 1)
+        state["hits"], state["best"] = hits, best
+        if world > 1:  # the path's one exchange step: every rank ends up with every frame's best-face rectangle
+            rec = hd.pack_best_records(best, f0, nf_max)
+            rec_local.copy_(torch.from_numpy(rec), non_blocking=False)
+            state["gathered"] = hd.allgather_records(rec_local, world, nf_max)
+            state["rec"] = rec
+        return best
+
+    def run_steps(k):
+        inflight = []
+        for i in range(k):
+            cx = ctxs[i % depth]
+            if len(inflight) == depth:
+                finish(inflight.pop(0))
+            cx.detect_enqueue(a.flags)
+            inflight.append(cx)
+        while inflight:
+            finish(inflight.pop(0))
+
+    # ~0.2 s of the same work before the W warm-up steps so that clocks, allocator and page tables are in their steady
+    # state whatever W the caller chose (a 3-step warm-up is 1 ms of GPU time; a cold first run measured up to 10 % slower)
+    if prewarm > 0:
+        t_pre = time.perf_counter()
+        while time.perf_counter() - t_pre < prewarm:
+            run_steps(8 * depth)
+    run_steps(max(warmup, depth))
+    env.fence()
+    t0 = time.perf_counter()
+    run_steps(steps)
+    env.fence()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    fps = total * steps / dt
+
+    gather_ok = None
+    if world > 1:  # outside the timed region: the gathered tensor must be the concatenation of every rank's own records
+        mine = state["rec"]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        if rank == 0:
+            got = state["gathered"].cpu().numpy()
+            gather_ok = all(np.array_equal(got[r], everyone[r]) for r in range(world))
+            if not gather_ok:
+                raise SystemExit("all-gather mismatch: gathered best-face records differ from the per-rank results")
+    if rank != 0:
+        for cx in ctxs:
+            cx.close()
+        return None
+
+    # ---- roofline of the dominant kernel: live HIP-event timing on the ctx stream --------------------------------------
+    ctx.profile(True)
+    ctx.kernel_times(reset=True)
+    psteps = max(3, min(10, steps))
+    for _ in range(psteps):
+        ctx.detect_enqueue(a.flags)
+        ctx.detect_collect(cap=1 << 17)
+    kt = ctx.kernel_times(reset=True)
+    ctx.profile(False)
+    per_step = {k: v["ms"] / psteps for k, v in kt.items()}
+    per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items()}
+    # "dominant kernel" = the longest single launch (the unit the roofline formula is written in).  k_resample runs several
+    # dependent launches per step, each over a different slice of the pyramid; its total per step is in kernel_ms_per_step.
+    dom = max(per_launch, key=per_launch.get)
+    P = ctx.pyramid_bytes_per_frame
+    b_detect = 4 * W * H + 2 * P  # SURVEY.md §8(d): read RGBA once, write each gray plane once, read it once in the scan
+    launches_per_step = kt[dom]["launches"] / psteps
+    achieved = b_detect * nf / launches_per_step / (per_launch[dom] * 1e-3) / 1e9
+    all_traffic = load_traffic(name)
+    roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
+                    traffic=all_traffic.get(dom) if (nf, scaling) == (nf_default, "weak") else None,
+                    algorithmic_bytes_per_frame=b_detect, frames_per_launch=nf, avg_launch_ms=round(per_launch[dom], 5))
+    dev_ms = sum(per_step.values())
+    rec = {
+        "value": round(fps, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "scaling": scaling,
+        "config": {"workload": WORKLOAD_TEXT[name], "frames_per_gpu": nf, "frames_total": total, "batches_in_flight": depth, "width": W, "height": H,
+                   "unique_frames": uniq, "frame_mix": "1/3 LCG noise, 1/3 smooth, 1/3 faces",
+                   "parallelism": f"frames block-sharded over {world} GPU(s), all-gather of {nf_max}x64B best-face rect records (verified against the per-rank results)" if world > 1 else "1 GPU"},
+        "roofline": roofline,
+    }
+    if gather_ok is not None:
+        rec["allgather_verified"] = bool(gather_ok)
+    # each kernel against its OWN algorithmic bytes (per step): gray 5*W*H, pyramid build 2*(P - W*H) (every derived plane
+    # written once, its source read once), tile scan P (every plane read once)
+    own = {"gray": 5 * W * H * nf, "resample": 2 * (P - W * H) * nf, "scan_tiles": P * nf}
+    rec["kernel_ms_per_step"] = {k: round(v, 5) for k, v in per_step.items()}
+    rec["kernel_rooflines"] = {k: dict(own_bytes_per_step=own[k], gbs=round(own[k] / (per_step[k] * 1e-3) / 1e9, 1),
+                                       frac=round(own[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) for k in own if k in per_step}
+    rec["device_ms_per_step"] = round(dev_ms, 5)
+    rec["path_hbm_gbs"] = round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2)
+    rec["path_hbm_frac"] = round(b_detect * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    rec["hits_per_step"] = int(len(state["hits"]))
+    rec["faces_per_step"] = int((state["best"]["neighbors"] > 0).sum())
+    if full:
+        ctx.detect_enqueue(a.flags | 16)  # one extra untimed pass with HT_SCAN_STATS for the survival curve
+        ctx.detect_collect(cap=1 << 17)
+        sc = ctx.stage_counts()
+        per_stage = [int(v) for v in ctx.cascade.stages["count"]]
+        feat_evals = sum(int(sc[j]) * per_stage[j] for j in range(len(per_stage)))
+        rec.update(feature_evals_per_s=round(feat_evals / (dev_ms * 1e-3), 1), windows_per_frame=int(ctx.windows_per_frame),
+                   windows_per_s=round(float(sc[0]) / (dev_ms * 1e-3), 1), stage_in=[int(v) for v in sc])
+    if world == 1 and cpu_seconds > 0:
+        frames = base[np.arange(min(nf, 64)) % uniq]
+        cpu, port = cpu_detect_baseline(frames, W, H, ctx.cascade.blob, cpu_seconds)
+        rec["cpu_baseline"], rec["cpu_baseline_port"] = cpu, port
+        rec["vs_cpu"] = round(fps / cpu["value"], 1)
+    else:
+        rec["cpu_baseline"] = None
+    for cx in ctxs:
+        cx.close()
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C3: detect once + 60 camshift track() calls per stream
+
+
+def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
+    torch, rank, world, local = env.torch, env.rank, env.world, env.local
+    from headtrackr_amd import synth
+    from headtrackr_amd.api import Context
+
+    W, H, nf = GEOM["c3"]
+    nf = a.frames or nf
+    # family F only (SURVEY.md §8d): every stream has one face; NV versions of each stream's frame with the face moved by a
+    # seeded <= 3 px walk; track() call i sees version (i + 1) % NV
+    NV, CALLS = 4, 60
+    walk = synth.lcg_stream(4242 + rank, 2 * NV * nf).astype(np.int64) >> 20
+    vers = np.empty((NV, nf, H, W, 4), dtype=np.uint8)
+    for f in range(nf):
+        s0 = 48 + (f * 7) % 80
+        x, y = 20 + (f * 13) % (W - s0 - 40), 16 + (f * 29) % (H - s0 - 32)
+        for v in range(NV):
+            vers[v, f] = synth.face_frame(W, H, [(x, y, s0)])
+            x += int(walk[2 * (f * NV + v)] % 7) - 3
+            y += int(walk[2 * (f * NV + v) + 1] % 7) - 3
+    dev_vers = [torch.from_numpy(vers[v]).cuda() for v in range(NV)]
+    ctx = Context(device=local)
+    ctx.set_geometry(W, H, nf)
+    ctx.bind_device(dev_vers[0].data_ptr(), nf, W * H * 4)
+    ctx.camshift_reserve(nf)
+    seq_ptrs = [dev_vers[(it + 1) % NV].data_ptr() for it in range(CALLS)]
+    state = {}
+
+    def step():
+        ctx.detect_enqueue(a.flags)
+        hits, counts = ctx.detect_collect(cap=1 << 17)
+        best = ctx.best_faces(hits, counts, 1)  # facetrackr.js:147-175 for the whole batch
+        fl = np.floor(np.stack([best["x"], best["y"], best["width"], best["height"]], axis=1)).astype(np.int64)  # facetrackr.js:101-106
+        rects = [tuple(fl[f]) if best["neighbors"][f] > 0 else (W // 4, H // 4, W // 2, H // 2) for f in range(nf)]
+        ctx.camshift_init(rects)
+        tracked = ctx.camshift_track_sequence(seq_ptrs, nf, calc_angles=True)  # 60 calls, one host call, last result fetched
+        state.update(best=best, tracked=tracked, rects=rects)
+
+    for _ in range(max(warmup, 1)):
+        step()
+    env.fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    env.fence()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
+    total_frames = world * nf * steps * (CALLS + 1)  # every processed frame: 1 detected + 60 tracked per stream and step
+    if rank != 0:
+        ctx.close()
+        return None
+    # camshift roofline: HIP-event timing of the two track kernels + the window pixels actually visited
+    ctx.camshift_stats(nf, reset=True)
+    ctx.profile(True)
+    ctx.kernel_times(reset=True)
+    ctx.camshift_init(state["rects"])
+    ctx.camshift_track_sequence(seq_ptrs, nf, calc_angles=True)
+    kt = ctx.kernel_times(reset=True)
+    ctx.profile(False)
+    px, calls = ctx.camshift_stats(nf, reset=True)
+    win_px_per_call = float(px.sum()) / max(float(calls.sum()), 1.0)
+    b_track = 4 * W * H + 4 * win_px_per_call  # SURVEY.md §8(d): one full-frame histogram pass + the window passes, per stream and call
+    per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items() if k in ("cs_hist", "cs_meanshift")}
+    dom = max(per_launch, key=per_launch.get)
+    call_ms = sum(per_launch.values())
+    achieved = b_track * nf / (per_launch[dom] * 1e-3) / 1e9
+    own = {"cs_hist": 4 * W * H * nf, "cs_meanshift": 4 * win_px_per_call * nf}
+    rec = {
+        "value": round(total_frames / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "scaling": "weak",
+        "config": {"workload": WORKLOAD_TEXT["c3"], "streams_per_gpu": nf, "track_calls_per_step": CALLS, "width": W, "height": H,
+                   "frame_mix": "family F only: one vote-image face per stream, moved by a seeded <= 3 px walk over 4 frame versions",
+                   "host_calls_per_step": "ht_detect_enqueue/collect + ht_best_faces + ht_camshift_init_batch + ONE ht_camshift_track_sequence (60 calls)"},
+        "roofline": dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                         algorithmic_bytes_per_stream_call=round(b_track, 1), window_pixels_per_call=round(win_px_per_call, 1), streams_per_launch=nf,
+                         avg_launch_ms=round(per_launch[dom], 5)),
+        "kernel_ms_per_track_call": {k: round(v, 5) for k, v in per_launch.items()},
+        "kernel_rooflines": {k: dict(own_bytes_per_call=round(own[k]), gbs=round(own[k] / (per_launch[k] * 1e-3) / 1e9, 1),
+                                     frac=round(own[k] / (per_launch[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) for k in per_launch},
+        "track_path_hbm_frac": round(b_track * nf / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "track_calls_per_s_device": round(nf / (call_ms * 1e-3), 1),
+        "detected": int((state["best"]["neighbors"] > 0).sum()), "alive": int((state["tracked"]["width"] > 0).sum()),
+    }
+    if world == 1 and cpu_seconds > 0:
+        f = int(np.argmax(state["best"]["neighbors"] > 0))
+        cpu = cpu_camshift_baseline(vers[:, f], state["rects"][f], W, H, cpu_seconds)
+        rec["cpu_baseline"] = cpu
+        rec["vs_cpu_track_calls"] = round(rec["track_calls_per_s_device"] / cpu["value"], 1)
+    else:
+        rec["cpu_baseline"] = None
+    ctx.close()
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C5: streaming feeds
+
+
+def stream_bench(env, a):
     """C5 (BASELINE.json configs[4]): one live 1920x1080 feed per GPU; every frame travels host -> GPU (pinned buffer,
     PCIe) -> result on the host.  Frame 0, 30, 60, ... : full-cascade detect + camshift.initTracker on the best face
     (facetrackr.js:97-108); every other frame: camshift.track.  A step is one frame of every feed; reports aggregate
     frames/s and the per-frame end-to-end latency distribution."""
+    torch, dist, rank, world, local = env.torch, env.dist, env.rank, env.world, env.local
     from headtrackr_amd import synth
     from headtrackr_amd.api import Context
 
@@ -95,25 +483,56 @@ def stream_bench(a, torch, dist, rank, world, local):
     # crosses PCIe on the copy stream while frame i is processed
     ctx.upload_async_ptr(host.data_ptr(), 1)
     ctx.swap_frames()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    env.fence()
     t0 = time.perf_counter()
     for i in range(steps):
         ctx.upload_async_ptr(host.data_ptr() + ((i + 1) % nuniq) * fbytes, 1)
         last = process(i)
         ctx.swap_frames()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    env.fence()
+    dt = env.max_over_ranks(time.perf_counter() - t0)
     if rank == 0:
         allv = np.array(lat["detect"] + lat["track"])
         pct = lambda v, q: round(float(np.percentile(np.array(v), q)), 4) if len(v) else None  # noqa: E731
+        # roofline of one 30-frame cycle (1 detect + 29 track), live HIP events on the ctx stream
+        ctx.camshift_stats(1, reset=True)
+        ctx.profile(True)
+        ctx.kernel_times(reset=True)
+        for i in range(30):
+            ctx.upload_ptr(host.data_ptr() + (i % nuniq) * fbytes, 1)
+            process(i)
+        kt = ctx.kernel_times(reset=True)
+        ctx.profile(False)
+        px, calls = ctx.camshift_stats(1, reset=True)
+        per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items()}
+        det = {k: v for k, v in per_launch.items() if k in ("gray", "resample", "scan_tiles", "scan_deep")}
+        dom = max(det, key=det.get)
+        P = ctx.pyramid_bytes_per_frame
+        b_detect = 4 * W * H + 2 * P
+        ach = b_detect / (det[dom] * 1e-3) / 1e9
+        win = float(px[0]) / max(float(calls[0]), 1.0)
+        b_track = 4 * W * H + 4 * win
+        cs = {k: v for k, v in per_launch.items() if k in ("cs_hist", "cs_meanshift")}
+        cdom = max(cs, key=cs.get)
+        cach = b_track / (cs[cdom] * 1e-3) / 1e9
+        roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+                        algorithmic_bytes_per_frame=b_detect, frames_per_launch=1, avg_launch_ms=round(det[dom], 5),
+                        note="a single 1080p frame per launch cannot fill 256 CUs x 5 workgroups: latency-, not bandwidth-bound by construction")
+        cs_roofline = dict(bound="hbm", kernel=cdom, achieved=round(cach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(cach / HBM_PEAK_GBS, 5), traffic=None,
+                           algorithmic_bytes_per_stream_call=round(b_track, 1), window_pixels_per_call=round(win, 1), avg_launch_ms=round(cs[cdom], 5))
+        dev_ms = {k: round(v["ms"], 4) for k, v in kt.items()}
+        cpu = None
+        if world == 1 and a.cpu_seconds > 0:
+            # the reference JS on the same feed: detect on one 1080p frame, camshift.track on the following ones; a 30-frame cycle
+            # = 1 detect + 29 track calls (facetrackr's state machine after the white-balance phase)
+            fr = np.ascontiguousarray(hv[:4])
+            cd, _ = cpu_detect_baseline(fr[:2], W, H, ctx.cascade.blob, a.cpu_seconds * 0.6)
+            bx = [int(np.floor(v)) for v in (700, 300, 360, 360)]
+            ct = cpu_camshift_baseline(fr, bx, W, H, a.cpu_seconds * 0.4)
+            cyc = 1.0 / cd["value"] + 29.0 / ct["value"]
+            cpu = dict(value=round(30.0 / cyc, 3), unit="frames/s", cores=1, kind=cd["kind"] if cd["kind"] == ct["kind"] else "mixed",
+                       sample=f"one feed, 30-frame cycle = 1 detect ({cd['value']} frames/s: {cd['sample']}) + 29 camshift track ({ct['value']} calls/s: {ct['sample']})",
+                       host_cpus=cd.get("host_cpus"))
         print(json.dumps({
             "metric": "frames/sec streaming 1920x1080 feeds (detect every 30th frame, camshift between), end to end incl. PCIe (double-buffered ingest)",
             "value": round(world * steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
@@ -125,10 +544,9 @@ def stream_bench(a, torch, dist, rank, world, local):
             "latency_ms": {"p50": pct(allv, 50), "p99": pct(allv, 99), "detect_p50": pct(lat["detect"], 50), "detect_max": pct(lat["detect"], 100),
                            "track_p50": pct(lat["track"], 50), "track_p99": pct(lat["track"], 99)},
             "last_track": [float(last["x"]), float(last["y"]), float(last["width"]), float(last["height"])],
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": roofline, "camshift_roofline": cs_roofline, "device_ms_per_30_frame_cycle": dev_ms,
+            "cpu_baseline": cpu, "vs_cpu": round(world * steps / dt / cpu["value"], 1) if cpu else None}), flush=True)
     ctx.close()
-    if world > 1:
-        dist.destroy_process_group()
 
 
 def main():
@@ -147,267 +565,43 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-
-    from headtrackr_amd import distributed as hd
-    from headtrackr_amd import synth
-    from headtrackr_amd.api import Context
+    env = Env(torch, dist, rank, world, local)
+    t_run = time.perf_counter()
 
     if a.workload == "c5":
-        return stream_bench(a, torch, dist, rank, world, local)
-
-    if a.workload == "c4":
-        W, H, nf = 1280, 720, a.frames or 128
-        uniq = a.unique or 12
+        stream_bench(env, a)
     else:
-        W, H, nf = 320, 240, a.frames or 256
-        uniq = a.unique or nf
-    uniq = min(uniq, nf)
-    # frame i of rank r is synthetic frame (r*nf + i) mod uniq of the N/S/F mix
-    if a.workload == "c3":
-        # C3: family F only — every stream has one face; 4 versions of each stream's frame with the face
-        # moved by a seeded <= 3 px walk; track() call i sees version i % 4
-        NV = 4
-        walk = synth.lcg_stream(4242 + rank, 2 * NV * nf).astype(np.int64) >> 20
-        vers = np.empty((NV, nf, H, W, 4), dtype=np.uint8)
-        for f in range(nf):
-            s0 = 48 + (f * 7) % 80
-            x, y = 20 + (f * 13) % (W - s0 - 40), 16 + (f * 29) % (H - s0 - 32)
-            for v in range(NV):
-                vers[v, f] = synth.face_frame(W, H, [(x, y, s0)])
-                x += int(walk[2 * (f * NV + v)] % 7) - 3
-                y += int(walk[2 * (f * NV + v) + 1] % 7) - 3
-        frames = vers[0]
-        dev_vers = [torch.from_numpy(vers[v]).cuda() for v in range(NV)]
-        dev = dev_vers[0]
-    else:
-        base = synth.mixed_batch(uniq, W, H, seed0=1234 + 1000 * rank)
-        frames = base[np.arange(nf) % uniq]
-        dev = torch.from_numpy(frames).cuda()  # resident in HBM before the timed region
-    # every step is one full pass over the batch with its results collected on the host; with --pipeline 2 the next
-    # step is enqueued (on a second context / HIP stream) before the previous one is collected, so the host-side
-    # collect + sort of step i overlaps the GPU work of step i+1.  All K steps are collected inside the timed region.
-    depth = 1 if a.workload == "c3" else max(1, a.pipeline)
-    ctxs = []
-    for _ in range(depth):
-        cx = Context(device=local)
-        cx.set_geometry(W, H, nf)
-        cx.bind_device(dev.data_ptr(), nf, W * H * 4)
-        ctxs.append(cx)
-    ctx = ctxs[0]
-    if a.workload == "c3":
-        ctx.camshift_reserve(nf)
-
-    rec_local = torch.zeros((nf, hd.RECORD_F64), dtype=torch.float64, device="cuda")
-
-    def finish(cx):
-        hits, counts = cx.detect_collect(cap=1 << 16)
-        if world > 1:  # the path's one exchange step: every rank ends up with every frame's best-face record
-            rec_local.copy_(torch.from_numpy(hd.pack_records(hits, counts, nf)), non_blocking=False)
-            hd.allgather_records(rec_local, world, nf)
-        return hits, counts
-
-    def run_steps(k):
-        inflight = []
-        last = None
-        for i in range(k):
-            cx = ctxs[i % depth]
-            if len(inflight) == depth:
-                last = finish(inflight.pop(0))
-            cx.detect_enqueue(a.flags)
-            inflight.append(cx)
-        while inflight:
-            last = finish(inflight.pop(0))
-        return last
-
-    c3_state = {}
-
-    def step():
-        ctx.detect_enqueue(a.flags)
-        hits, counts = ctx.detect_collect(cap=1 << 16)
         if a.workload == "c3":
-            # detect once, initTracker on the best face, then 60 camshift track() calls on the moving frames
-            best = ctx.best_faces(hits, counts, 1)  # facetrackr.js:147-175 for the whole batch
-            fl = np.floor(np.stack([best["x"], best["y"], best["width"], best["height"]], axis=1)).astype(np.int64)  # facetrackr.js:101-106
-            rects = [tuple(fl[f]) if best["neighbors"][f] > 0 else (W // 4, H // 4, W // 2, H // 2) for f in range(nf)]
-            ctx.camshift_init(rects)
-            for it in range(60):
-                ctx.bind_device(dev_vers[(it + 1) % NV].data_ptr(), nf, W * H * 4)
-                tracked = ctx.camshift_track(nf, calc_angles=True, fetch=(it == 59))
-            ctx.bind_device(dev.data_ptr(), nf, W * H * 4)
-            c3_state["detected"] = int((best["neighbors"] > 0).sum())
-            c3_state["alive"] = int((tracked["width"] > 0).sum())
-        if world > 1:  # the path's one exchange step: every rank ends up with every frame's best-face record
-            rec_local.copy_(torch.from_numpy(hd.pack_records(hits, counts, nf)), non_blocking=False)
-            hd.allgather_records(rec_local, world, nf)
-        return hits, counts
-
-    # setup, before the W warm-up steps: ~0.2 s of the same work so that clocks, the allocator and the page tables are in
-    # their steady state whatever W the caller chose (a 3-step warm-up is 1 ms of GPU time; a cold first run measured
-    # up to 10 % slower)
-    if a.workload != "c3" and a.prewarm > 0:
-        t_pre = time.perf_counter()
-        while time.perf_counter() - t_pre < a.prewarm:
-            run_steps(8 * depth)
-    if a.workload == "c3":
-        for _ in range(a.warmup):
-            hits, counts = step()
-    else:
-        hits, counts = run_steps(max(a.warmup, depth))
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    if a.workload == "c3":
-        for _ in range(a.steps):
-            hits, counts = step()
-    else:
-        hits, counts = run_steps(a.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    # C3 counts every processed frame: 1 detected + 60 tracked per stream and step
-    total_frames = world * nf * a.steps * (61 if a.workload == "c3" else 1)
-    fps = total_frames / dt
-
-    # ---- roofline of the dominant kernel: live HIP-event timing on the ctx stream (rank 0) ----------------------
-    roofline = None
-    extra = {}
-    if rank == 0:
-        ctx.profile(True)
-        ctx.kernel_times(reset=True)
-        psteps = max(3, min(10, a.steps))
-        for _ in range(psteps):
-            ctx.detect_enqueue(a.flags)
-            ctx.detect_collect(cap=1 << 16)
-        kt = ctx.kernel_times(reset=True)
-        ctx.profile(False)
-        per_step = {k: v["ms"] / psteps for k, v in kt.items()}
-        per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items()}
-        # "dominant kernel" = the longest single launch (the unit the roofline formula is written in).  k_resample runs 7
-        # dependent launches per step, each over a different slice of the pyramid; its total per step is listed in
-        # kernel_ms_per_step and its own-bytes roofline in kernel_rooflines.
-        dom = max(per_launch, key=per_launch.get)
-        P = ctx.pyramid_bytes_per_frame
-        b_detect = 4 * W * H + 2 * P  # read RGBA once, write each gray plane once, read it once in the scan
-        launches_per_step = kt[dom]["launches"] / psteps
-        avg_launch_ms = per_launch[dom]
-        achieved = b_detect * nf / launches_per_step / (avg_launch_ms * 1e-3) / 1e9
-        traffic = None
-        all_traffic = {}
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                all_traffic = json.load(open(tf)).get(a.workload, {})
-                traffic = all_traffic.get(dom)
-            except Exception:
-                traffic = None
-        roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(achieved / HBM_PEAK_GBS, 5), traffic=traffic,
-                        algorithmic_bytes_per_frame=b_detect, avg_launch_ms=round(avg_launch_ms, 5))
-        # each kernel against its OWN algorithmic bytes (per step): gray 5*W*H, pyramid build 2*(P - W*H) (every derived plane
-        # written once, its source read once), tile scan P (every plane read once)
-        own = {"gray": 5 * W * H * nf, "resample": 2 * (P - W * H) * nf, "scan_tiles": P * nf}
-        kernel_rooflines = {k: dict(own_bytes_per_step=own[k], gbs=round(own[k] / (per_step[k] * 1e-3) / 1e9, 1),
-                                    frac=round(own[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                    hbm_traffic_per_launch=all_traffic.get(k)) for k in own if k in per_step}
-        dev_ms = sum(per_step.values())
-        ctx.detect_enqueue(a.flags | 16)  # one extra untimed pass with HT_SCAN_STATS for the survival curve
-        ctx.detect_collect(cap=1 << 16)
-        sc = ctx.stage_counts()
-        # a device-copy ceiling measured in the same run (what a kernel that only reads and writes HBM
-        # reaches on this box), and feature evaluations per second from the survival curve
-        buf = torch.empty(1 << 29, dtype=torch.uint8, device="cuda")
-        dst = torch.empty_like(buf)
-        dst.copy_(buf)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(8):
-            dst.copy_(buf)
-        e1.record()
-        torch.cuda.synchronize()
-        copy_gbs = 2.0 * buf.numel() * 8 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-        del buf, dst
-        roofline["device_copy_gbs"] = round(copy_gbs, 1)
-        roofline["frac_of_device_copy"] = round(achieved / copy_gbs, 5)
-        per_stage = [int(v) for v in ctx.cascade.stages["count"]]
-        feat_evals = sum(int(sc[j]) * per_stage[j] for j in range(len(per_stage)))
-        extra = dict(feature_evals_per_s=round(feat_evals / (dev_ms * 1e-3), 1),
-                     kernel_ms_per_step={k: round(v, 5) for k, v in per_step.items()}, kernel_rooflines=kernel_rooflines,
-                     device_ms_per_step=round(dev_ms, 5),
-                     path_hbm_gbs=round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2),
-                     path_hbm_frac=round(b_detect * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                     windows_per_frame=int(ctx.windows_per_frame),
-                     windows_per_s=round(float(sc[0]) / (dev_ms * 1e-3), 1),
-                     hits_per_step=int(len(hits)), stage_in=[int(v) for v in sc])
-
-    # ---- CPU baselines on the box's host cores (rank 0, N = 1 only), bounded samples of the same frames ------------------
-    #  * "reference": the UNMODIFIED reference JS, single-threaded Node (its own execution model), from oracle/_ref
-    #  * "port":      the plain-C oracle restatement, 1 thread
-    cpu = None
-    cpu_port = None
-    if rank == 0 and world == 1 and a.cpu_seconds > 0:
-        import shutil
-        import subprocess
-        import tempfile
-
-        from oracle import ht_oracle as ho
-
-        blob = ctx.cascade.blob
-        ho.detect_raw(frames[0], blob)  # warm
-        t0 = time.perf_counter()
-        done = 0
-        while done < nf and (done < 4 or time.perf_counter() - t0 < a.cpu_seconds):
-            ho.detect_raw(frames[done], blob)
-            done += 1
-        cdt = time.perf_counter() - t0
-        cpu_port = dict(value=round(done / cdt, 3), unit="frames/s", cores=1, kind="port",
-                        sample=f"first {done} of the {nf} {W}x{H} frames of this workload, oracle/ht_oracle.c detect (gray+pyramid+scan), 1 thread",
-                        host_cpus=os.cpu_count())
-        cpu = cpu_port
-        gz = os.path.join(ROOT, "oracle", "_ref", "headtrackr_ref.js.gz")
-        node = shutil.which("node")
-        if node and os.path.exists(gz):
-            try:
-                ns = min(nf, 64)
-                with tempfile.NamedTemporaryFile(suffix=".raw") as tf:
-                    frames[:ns].tofile(tf.name)
-                    r = subprocess.run([node, os.path.join(ROOT, "oracle", "ref_bench.js"), tf.name, str(ns), str(W), str(H), str(a.cpu_seconds)],
-                                       capture_output=True, text=True, timeout=a.cpu_seconds * 6 + 120)
-                j = json.loads(r.stdout.strip().splitlines()[-1])
-                cpu = dict(value=round(j["fps"], 3), unit="frames/s", cores=1, kind="reference",
-                           sample=f"first {j['frames']} of the {nf} {W}x{H} frames of this workload: unmodified reference JS (ccv.grayscale + ccv.detect_objects(..., 5, 1)) "
-                                  f"on oracle/canvas_shim.js, {j['node']} single thread, median {j['ms_median']:.1f} ms/frame, {100 * j['shim_fraction']:.0f}% of it inside the canvas shim",
-                           host_cpus=j["cpus"], cpu_model=j["cpu_model"])
-            except Exception as e:  # the port baseline stands in
-                cpu = dict(cpu_port, note=f"reference JS baseline unavailable: {e}")
-
-    if rank == 0:
-        line = {
-            "metric": f"frames/sec {'(1 full-cascade detect + 60 camshift track per stream)' if a.workload == 'c3' else 'full-cascade detect'} at {W}x{H}",
-            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": {"c2": "C2: 256 x 320x240 RGBA frames per GPU, full BBF cascade detect (interval 5), raw hits to host",
-                                    "c3": "C3: 256 streams of 320x240 per GPU (one moving face each): detect once, initTracker, then 60 camshift track() calls; every processed frame counts",
-                                    "c4": "C4: 1280x720 frames, 128 per GPU (1024 on 8 GPUs), full cascade detect + all-gather of best-face records"}[a.workload],
-                       "frames_per_gpu": nf, "batches_in_flight": depth, "width": W, "height": H, "unique_frames": uniq, "frame_mix": "1/3 LCG noise, 1/3 smooth, 1/3 faces",
-                       "parallelism": f"frames sharded over {world} GPU(s), all-gather of {nf}x64B records" if world > 1 else "1 GPU"},
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_port": cpu_port,
-        }
-        line.update(extra)
-        if c3_state:
-            line["c3"] = c3_state
-        print(json.dumps(line), flush=True)
-    for cx in ctxs:
-        cx.close()
+            prim = c3_bench(env, a, a.steps, a.warmup, a.cpu_seconds)
+            metric = "frames/sec (1 full-cascade detect + 60 camshift track per stream) at 320x240"
+        else:
+            prim = detect_bench(env, a, a.workload, a.steps, a.warmup, scaling=a.scaling, frames_per_gpu=a.frames, cpu_seconds=a.cpu_seconds, prewarm=a.prewarm)
+            W, H, _ = GEOM[a.workload]
+            metric = f"frames/sec full-cascade detect at {W}x{H}"
+        sub = {}
+        if a.workload == "c2" and a.scaling == "weak" and not a.no_sub:
+            # the rest of BASELINE.json's metric in the same line: 1280x720 detect (per-GPU batch of configs[3]; weak and strong)
+            # and detect + camshift (configs[2]), each with its own bounded budget
+            tag = "c4_1gpu" if world == 1 else "c4"
+            sub[tag] = detect_bench(env, a, "c4", SUB_STEPS["c4"], 10, cpu_seconds=a.cpu_seconds, prewarm=0.1, full=False)
+            sub["c4_strong"] = detect_bench(env, a, "c4", SUB_STEPS["c4_strong"], 4, scaling="strong", cpu_seconds=0, full=False)
+            sub["c3"] = c3_bench(env, a, SUB_STEPS["c3"], 2, a.cpu_seconds * 0.7)
+        if rank == 0:
+            copy_gbs = device_copy_ceiling(torch)
+            for r in [prim] + [v for v in sub.values() if v]:
+                if r.get("roofline"):
+                    r["roofline"]["device_copy_gbs"] = round(copy_gbs, 1)
+                    r["roofline"]["frac_of_device_copy"] = round(r["roofline"]["achieved"] / copy_gbs, 5)
+            line = {"metric": metric, "value": prim["value"], "unit": "frames/s", "n_gpus": world, "steps": prim["steps"], "warmup": prim["warmup"],
+                    "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": prim["scaling"], "vs_baseline": None, "dtype": "u8",
+                    "data": "synthetic"}
+            line.update({k: v for k, v in prim.items() if k not in line})
+            if sub:
+                line["sub"] = sub
+                if sub.get("c4_1gpu") and sub["c4_1gpu"].get("vs_cpu"):
+                    line["north_star_720p_vs_reference_js"] = sub["c4_1gpu"]["vs_cpu"]  # target: >= 30x on 1280x720 detect at 1 GPU
+            line["bench_wall_s"] = round(time.perf_counter() - t_run, 1)
+            print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -187,6 +187,13 @@ class Context:
         self._check(self._lib.ht_grayscale_batch(self._h, out.ctypes.data, n, w, h, w * h * 4))
         return out
 
+    def detect_whitebalance(self, n: int | None = None) -> np.ndarray:
+        """getWhitebalance of the frames of the batch last enqueued with HT_DETECT_WHITEBALANCE (fused into the gray pass)."""
+        n = self.nframes if n is None else n
+        out = np.zeros(n, dtype=np.float64)
+        self._check(self._lib.ht_detect_whitebalance(self._h, out.ctypes.data, n))
+        return out
+
     def whitebalance(self) -> np.ndarray:
         """headtrackr.getWhitebalance for every bound frame."""
         out = np.zeros(self.nframes, dtype=np.float64)
@@ -207,6 +214,34 @@ class Context:
         out = np.zeros(n, dtype=native.CS_TRACKOBJ_DTYPE)
         self._check(self._lib.ht_camshift_track_batch(self._h, first, n, int(calc_angles), out.ctypes.data if fetch else None))
         return out
+
+    def camshift_track_sequence(self, dev_ptrs, n: int, calc_angles: bool = True, first: int = 0, frame_stride: int | None = None,
+                                fetch: str = "last"):
+        """len(dev_ptrs) successive track() calls in one host call; call k reads the n device-resident frames at dev_ptrs[k].
+        fetch: "last" -> [n] track objects of the last call, "all" -> [calls, n], "none" -> enqueue only."""
+        k = len(dev_ptrs)
+        ptrs = (C.c_void_p * k)(*[int(p) for p in dev_ptrs])
+        stride = frame_stride or self.width * self.height * 4
+        if fetch == "none":
+            self._check(self._lib.ht_camshift_track_sequence(self._h, first, n, int(calc_angles), ptrs, k, stride, None, 0))
+            return None
+        out = np.zeros((k, n) if fetch == "all" else (n,), dtype=native.CS_TRACKOBJ_DTYPE)
+        self._check(self._lib.ht_camshift_track_sequence(self._h, first, n, int(calc_angles), ptrs, k, stride, out.ctypes.data, int(fetch == "all")))
+        return out
+
+    def camshift_stats(self, n: int, first: int = 0, reset: bool = True):
+        """(window pixels read by the moment passes, track() calls) per stream since the last reset (SURVEY.md 8d B_track)."""
+        px = np.zeros(n, dtype=np.uint64)
+        calls = np.zeros(n, dtype=np.uint64)
+        self._check(self._lib.ht_camshift_stats(self._h, first, n, px.ctypes.data, calls.ctypes.data, int(reset)))
+        return px, calls
+
+    def camshift_debug_hist(self, stream: int, current: bool = True):
+        """(model histogram, full-frame histogram of the last track() call) of one stream, 4096 bins each (test hook)."""
+        model = np.zeros(4096, dtype=np.uint32)
+        cur = np.zeros(4096, dtype=np.uint32)
+        self._check(self._lib.ht_camshift_debug_hist(self._h, stream, model.ctypes.data, cur.ctypes.data if current else None))
+        return model, cur
 
     # -- measurement --------------------------------------------------------------------------------------------
     def profile(self, on: bool = True):

@@ -40,15 +40,18 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
     deps = srcs + [os.path.join(CSRC, "ht_internal.h"), os.path.join(CSRC, "ht_cascade_gen.inc"), os.path.join(ROOT, "include", "headtrackr_hip.h"), os.path.abspath(__file__)]
     if force or _newer(LIB, deps):
-        objs = []
-        for s in srcs:
+        objs, procs = [], []
+        for s in srcs:  # the translation units are independent: compile them side by side (ht_scan.hip alone takes ~1.5 min)
             o = os.path.splitext(s)[0] + ".o"
             if force or _newer(o, deps):
                 cmd = [HIPCC, *HIP_FLAGS, "-c", s, "-o", o]
                 if verbose:
                     print(" ".join(cmd))
-                subprocess.check_call(cmd)
+                procs.append((cmd, subprocess.Popen(cmd)))
             objs.append(o)
+        for cmd, p in procs:
+            if p.wait() != 0:
+                raise subprocess.CalledProcessError(p.returncode, cmd)
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-ldl"]
         if verbose:
             print(" ".join(cmd))

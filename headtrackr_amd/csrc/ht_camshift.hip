@@ -76,6 +76,7 @@ __global__ __launch_bounds__(256) void k_cs_init(const uint8_t *__restrict__ fra
     if (threadIdx.x == 0) {
         st.sw[0] = r.x, st.sw[1] = r.y, st.sw[2] = r.width, st.sw[3] = r.height;  // camshift.js:209
         st.x = st.y = st.width = st.height = st.angle = 0.0;                         // camshift.js:210
+        st.win_px = st.calls = 0;
     }
 }
 
@@ -220,11 +221,13 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
     Mom m = {0, 0, 0, 0, 0, 0};
     bool have_second = false;
     int wadx = 0, wady = 0, wadw = 0, wadh = 0;
+    unsigned long long visited = 0;  // window pixels read by the moment passes (B_track = 4*W*H + 4*sum(window))
     for (int it = 0; it < 10; it++) {  // camshift.js:284-306 (every thread runs the identical scalar logic)
         wadx = max(swx, 0);
         wady = max(swy, 0);
         wadw = min(wadx + sww, W);
         wadh = min(wady + swh, H);
+        visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
         if (it == 9) {
             m = window_moments<true>(img, W, lut, wadx, wady, wadw, wadh, red);
             have_second = true;
@@ -235,7 +238,10 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
         swx += toint32(xc - (double)sww / 2);                                    // camshift.js:295
         swy += toint32(yc - (double)swh / 2);                                    // camshift.js:296
         if (swx == prevx && swy == prevy) {                                      // camshift.js:299-301
-            if (!have_second) m = window_moments<true>(img, W, lut, wadx, wady, wadw, wadh, red);
+            if (!have_second) {
+                m = window_moments<true>(img, W, lut, wadx, wady, wadw, wadh, red);
+                visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
+            }
             have_second = true;
             break;
         }
@@ -268,6 +274,8 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
     const int nsww = (int)floor(1.1 * width), nswh = (int)floor(1.1 * height);  // camshift.js:257-258
     st.sw[0] = swx, st.sw[1] = swy, st.sw[2] = nsww, st.sw[3] = nswh;
     st.x = tx, st.y = ty, st.width = width, st.height = height, st.angle = angle;
+    st.win_px += visited;
+    st.calls += 1;
     if (out) {
         ht_cs_trackobj o;
         o.x = tx, o.y = ty, o.width = width, o.height = height, o.angle = angle;
@@ -317,29 +325,105 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
     return HT_OK;
 }
 
+// one track() call of streams [first, first + n) on frames[0..n): histogram pass + mean-shift, results to d_out[0..n)
+static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_stride, int32_t first, int32_t n, int32_t calc_angles,
+                              ht_cs_trackobj *d_out) {
+    const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
+    uint32_t chunk_px, nchunks;
+    hist_chunks(npix, hist_max_chunks(c->cs_streams), &chunk_px, &nchunks);  // buffer sized for cs_streams x that many chunks
+    {
+        HtProfScope ps(c, "cs_hist");
+        hipLaunchKernelGGL(k_cs_hist, dim3(nchunks, n), dim3(HIST_NT), 0, c->stream, frames, frame_stride, npix, chunk_px, c->d_cs_hist);
+        HT_HIP(c, hipGetLastError());
+    }
+    {
+        HtProfScope ps(c, "cs_meanshift");
+        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), 0, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_hist, (int)nchunks, c->d_cs,
+                           first, calc_angles, d_out);
+        HT_HIP(c, hipGetLastError());
+    }
+    c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = (int)nchunks;
+    return HT_OK;
+}
+
 extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n, int32_t calc_angles, ht_cs_trackobj *out) {
     if (!c) return HT_ERR_INVALID;
     if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_batch: bind n frames first");
     if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_track_batch: stream range not reserved");
     if (c->W == 0 || c->H == 0) return HT_OK;  // camshift.js:219
     HT_HIP(c, hipSetDevice(c->device));
-    const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
-    uint32_t chunk_px, nchunks;
-    hist_chunks(npix, hist_max_chunks(c->cs_streams), &chunk_px, &nchunks);  // buffer sized for cs_streams x that many chunks
-    {
-        HtProfScope ps(c, "cs_hist");
-        hipLaunchKernelGGL(k_cs_hist, dim3(nchunks, n), dim3(HIST_NT), 0, c->stream, c->d_frames, c->frame_stride, npix, chunk_px, c->d_cs_hist);
-        HT_HIP(c, hipGetLastError());
-    }
-    {
-        HtProfScope ps(c, "cs_meanshift");
-        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, c->d_cs_hist, (int)nchunks, c->d_cs,
-                           first, calc_angles, c->d_cs_out);
-        HT_HIP(c, hipGetLastError());
-    }
+    ht_status st = launch_track(c, c->d_frames, c->frame_stride, first, n, calc_angles, c->d_cs_out);
+    if (st != HT_OK) return st;
     if (out) {
         HT_HIP(c, hipMemcpyAsync(out, c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         HT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return HT_OK;
+}
+
+extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_t n, int32_t calc_angles, const void *const *dev_frames,
+                                                int32_t ncalls, size_t frame_stride, ht_cs_trackobj *out, int32_t out_all) {
+    if (!c || !dev_frames) return HT_ERR_INVALID;
+    if (c->W == 0) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_sequence: call ht_set_geometry first");
+    if (n <= 0 || ncalls <= 0 || frame_stride < (size_t)c->W * c->H * 4 || (frame_stride & 3))
+        return ht_fail(c, HT_ERR_INVALID, "ht_camshift_track_sequence: bad stream count, call count or frame stride");
+    if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_track_sequence: stream range not reserved");
+    for (int k = 0; k < ncalls; k++)
+        if (!dev_frames[k] || ((uintptr_t)dev_frames[k] & 3)) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_track_sequence: bad frame pointer");
+    HT_HIP(c, hipSetDevice(c->device));
+    const size_t need = (size_t)n * (size_t)(out_all ? ncalls : 1);
+    if (c->cs_seq_cap < need) {
+        HT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_cs_seq_out) (void)hipFree(c->d_cs_seq_out);
+        c->d_cs_seq_out = nullptr;
+        c->cs_seq_cap = 0;
+        if (hipMalloc(&c->d_cs_seq_out, need * sizeof(ht_cs_trackobj)) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_track_sequence: hipMalloc failed");
+        c->cs_seq_cap = need;
+    }
+    // the calls of one stream are sequentially dependent (search window, camshift.js:257-258), the streams are not: 2 launches
+    // per call on the context's stream, no host round trip in between
+    for (int k = 0; k < ncalls; k++) {
+        ht_cs_trackobj *d_out = c->d_cs_seq_out + (out_all ? (size_t)k * n : 0);
+        ht_status st = launch_track(c, static_cast<const uint8_t *>(dev_frames[k]), frame_stride, first, n, calc_angles, d_out);
+        if (st != HT_OK) return st;
+    }
+    if (out) {
+        HT_HIP(c, hipMemcpyAsync(out, c->d_cs_seq_out, need * sizeof(ht_cs_trackobj), hipMemcpyDeviceToHost, c->stream));
+        HT_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    return HT_OK;
+}
+
+extern "C" ht_status ht_camshift_stats(ht_ctx *c, int32_t first, int32_t n, uint64_t *window_pixels, uint64_t *calls, int32_t reset) {
+    if (!c || n <= 0 || first < 0 || first + n > c->cs_streams) return HT_ERR_INVALID;
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    std::vector<unsigned long long> v((size_t)n * 2);  // {win_px, calls} of every stream: one strided copy
+    HT_HIP(c, hipMemcpy2D(v.data(), 16, &c->d_cs[first].win_px, sizeof(HtCsState), 16, (size_t)n, hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; i++) {
+        if (window_pixels) window_pixels[i] = v[2 * (size_t)i];
+        if (calls) calls[i] = v[2 * (size_t)i + 1];
+    }
+    if (reset) HT_HIP(c, hipMemset2D(&c->d_cs[first].win_px, sizeof(HtCsState), 0, 16, (size_t)n));
+    return HT_OK;
+}
+
+extern "C" ht_status ht_camshift_debug_hist(ht_ctx *c, int32_t stream, uint32_t *model, uint32_t *current) {
+    if (!c || stream < 0 || stream >= c->cs_streams) return HT_ERR_INVALID;
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    if (model) HT_HIP(c, hipMemcpy(model, c->d_cs[stream].model, sizeof(uint32_t) * 4096, hipMemcpyDeviceToHost));
+    if (current) {
+        if (stream < c->cs_last_first || stream >= c->cs_last_first + c->cs_last_n || c->cs_last_chunks <= 0)
+            return ht_fail(c, HT_ERR_STATE, "ht_camshift_debug_hist: the stream was not part of the last track call");
+        std::vector<uint32_t> part((size_t)c->cs_last_chunks * 4096);
+        HT_HIP(c, hipMemcpy(part.data(), c->d_cs_hist + (size_t)(stream - c->cs_last_first) * c->cs_last_chunks * 4096, part.size() * sizeof(uint32_t),
+                            hipMemcpyDeviceToHost));
+        for (int b = 0; b < 4096; b++) {
+            uint32_t v = 0;
+            for (int k = 0; k < c->cs_last_chunks; k++) v += part[(size_t)k * 4096 + b];
+            current[b] = v;
+        }
     }
     return HT_OK;
 }

@@ -162,6 +162,16 @@ static ht_status upload_cascade(ht_ctx *c) {
             mp = std::max(mp, std::max(np, nn));
         }
         st[j].maxpts = mp;
+        // The integer decision "S < thri  <=>  the reference's binary64 sum < threshold" (off an exact tie) needs the
+        // rounding error of the reference's SEQUENTIAL sum to stay below half the 1e-8 grid: |err| <= count * 2^-52 *
+        // sum|alpha|.  True for the trained cascade (alphas O(1): bound ~1e-11); a custom cascade with huge alphas takes
+        // the sequential binary64 path everywhere instead of silently diverging from ccv.js:186-222.
+        double sabs = 0.0;
+        for (uint32_t k = 0; k < st[j].count; k++) {
+            const HtBlobFeature &f = c->h_feats[st[j].first + k];
+            sabs += std::max(std::fabs(f.alpha[0]), std::fabs(f.alpha[1]));
+        }
+        if (!((double)st[j].count * 2.220446049250313e-16 * (sabs + std::fabs(st[j].threshold)) < 0.5e-8)) c->decimal_alphas = false;
     }
     HT_HIP(c, hipMalloc(&c->d_deep_feats, deep.size() * sizeof(HtDeepFeature)));
     HT_HIP(c, hipMalloc(&c->d_stages, st.size() * sizeof(HtDevStage)));
@@ -222,6 +232,12 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         const int v = atoi(e);
         if (v >= 1 && v <= 64) c->rs_group = v;
     }
+    // measurement / test knobs (never set in production), read once here — not on the launch path
+    if (const char *e = getenv("HT_DEBUG_STOP_STAGE")) c->dbg_stop_stage = atoi(e);
+    if (const char *e = getenv("HT_DEBUG_FORCE_EXACT")) c->dbg_force_exact = atoi(e);
+    if (const char *e = getenv("HT_DEBUG_DEEP_BIAS")) c->deep_bias = (uint32_t)atoi(e);
+    if (const char *e = getenv("HT_DEBUG_DEEP_V")) c->dbg_deep_v = atoi(e);
+    if (const char *e = getenv("HT_DEBUG_DEEP_GRID")) c->deep_grid = std::max(1, atoi(e));
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
     c->split_stage = std::min<uint32_t>(c->builtin_cascade ? 8u : 4u, c->nstages);
@@ -280,6 +296,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_cs) (void)hipFree(c->d_cs);
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
+    if (c->d_cs_seq_out) (void)hipFree(c->d_cs_seq_out);
     for (auto &t : c->timers)
         for (auto &p : t.pending) (void)hipEventDestroy(p.first), (void)hipEventDestroy(p.second);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -305,20 +322,10 @@ static double ht_scale_pow(int interval, int i) {
 
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
-extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, int32_t max_batch, const int32_t *level_dims,
-                                     int32_t nlevels_in) {
-    if (!c) return HT_ERR_INVALID;
-    if (width <= 0 || height <= 0 || width > 16384 || height > 16384 || max_batch <= 0)
-        return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: width/height must be 1..16384 and max_batch > 0");
-    HT_HIP(c, hipSetDevice(c->device));
+// Builds every table / allocation of one geometry.  On any failure the caller (ht_set_geometry) frees what was built and
+// leaves the context without a geometry, so a retry (e.g. with a smaller max_batch after HT_ERR_NOMEM) starts clean.
+static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int32_t max_batch, const int32_t *level_dims, int n, int upto) {
     const int next = c->next;
-    const int upto = (int)std::floor(std::log((double)std::min(c->cw, c->ch)) / std::log(ht_scale_of(c->interval)));  // ccv.js:112
-    const int n = upto + next * 2;  // ccv.js:113
-    if (n > HT_MAX_LEVELS) return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: too many pyramid levels");
-    if (level_dims && nlevels_in != n) return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: level_dims has the wrong number of levels");
-    if (c->W == width && c->H == height && c->max_batch >= max_batch && c->nlevels == n && !level_dims) return HT_OK;
-    HT_HIP(c, hipStreamSynchronize(c->stream));
-    free_geometry(c);
     c->W = width;
     c->H = height;
     c->max_batch = max_batch;
@@ -329,11 +336,9 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
     c->pyr_bytes = 0;
     for (int i = 0; i < n; i++) {
         HtDevLevel &L = c->h_levels[i];
-        if (level_dims) {
+        if (level_dims) {  // validated by ht_set_geometry
             L.w = level_dims[2 * i];
             L.h = level_dims[2 * i + 1];
-            if (L.w < 0 || L.h < 0 || L.w > width || L.h > height || (i == 0 && (L.w != width || L.h != height)))
-                return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: bad level_dims");
         } else if (i == 0) {
             L.w = width;
             L.h = height;
@@ -499,10 +504,40 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
     c->queue_capacity = (uint32_t)qc;
     if (hipMalloc(&c->d_queue, (size_t)qc * sizeof(HtQueueEntry)) != hipSuccess)
         return ht_fail(c, HT_ERR_NOMEM, "ht_set_geometry: hipMalloc(survivor queue) failed");
-    c->nframes = 0;
+    return HT_OK;
+}
+
+extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, int32_t max_batch, const int32_t *level_dims,
+                                     int32_t nlevels_in) {
+    if (!c) return HT_ERR_INVALID;
+    if (width <= 0 || height <= 0 || width > 16384 || height > 16384 || max_batch <= 0)
+        return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: width/height must be 1..16384 and max_batch > 0");
+    HT_HIP(c, hipSetDevice(c->device));
+    const int upto = (int)std::floor(std::log((double)std::min(c->cw, c->ch)) / std::log(ht_scale_of(c->interval)));  // ccv.js:112
+    const int n = upto + c->next * 2;  // ccv.js:113
+    if (n > HT_MAX_LEVELS) return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: too many pyramid levels");
+    if (level_dims && nlevels_in != n) return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: level_dims has the wrong number of levels");
+    if (level_dims)  // everything that can be rejected is rejected before the current geometry is torn down
+        for (int i = 0; i < n; i++) {
+            const int lw = level_dims[2 * i], lh = level_dims[2 * i + 1];
+            if (lw < 0 || lh < 0 || lw > width || lh > height || (i == 0 && (lw != width || lh != height)))
+                return ht_fail(c, HT_ERR_INVALID, "ht_set_geometry: bad level_dims");
+        }
+    if (c->W == width && c->H == height && c->max_batch >= max_batch && c->nlevels == n && !level_dims) return HT_OK;
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->copy_stream) HT_HIP(c, hipStreamSynchronize(c->copy_stream));
+    free_geometry(c);
+    // frames bound / uploaded for the old geometry (incl. a pending ht_upload_frames_async) do not survive a size change
+    c->nframes = c->enq_nframes = 0;
+    c->back_n = 0;
     c->d_frames = nullptr;
     c->enqueued = false;
-    return HT_OK;
+    const ht_status st = set_geometry_impl(c, width, height, max_batch, level_dims, n, upto);
+    if (st != HT_OK) {  // no half-built geometry: the early-out above must not fire on a retry
+        free_geometry(c);
+        c->W = c->H = c->max_batch = c->nlevels = c->upto = 0;
+    }
+    return st;
 }
 
 extern "C" int32_t ht_num_levels(const ht_ctx *c) { return c ? c->nlevels : 0; }
@@ -613,6 +648,19 @@ extern "C" ht_status ht_bind_frames_device(ht_ctx *c, const void *dev_rgba, int3
 // ---------------------------------------------------------------------------------------------------------
 // detect
 
+static ht_status wb_scratch(ht_ctx *c) {  // 4 u64 per frame: R, G, B channel sums (+ pad)
+    const size_t need = sizeof(unsigned long long) * 4 * (size_t)std::max(c->max_batch, 1);
+    if (c->d_scratch_bytes < need) {
+        HT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->d_scratch) (void)hipFree(c->d_scratch);
+        c->d_scratch = nullptr;
+        c->d_scratch_bytes = 0;
+        if (hipMalloc(&c->d_scratch, need) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "whitebalance scratch: hipMalloc failed");
+        c->d_scratch_bytes = need;
+    }
+    return HT_OK;
+}
+
 extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
     if (!c) return HT_ERR_INVALID;
     if (!c->d_frames || c->nframes <= 0) return ht_fail(c, HT_ERR_STATE, "ht_detect_enqueue: no frames bound");
@@ -620,11 +668,23 @@ extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
     HT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(HtCounters), c->stream));
     c->stats_enqueued = (flags & HT_SCAN_STATS) != 0;
     if (c->stats_enqueued) HT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS, c->stream));
-    ht_status st = ht_launch_pyramid(c, flags);
+    ht_status st;
+    c->wb_fused = false;
+    c->wb_enqueued = false;
+    if (flags & HT_DETECT_WHITEBALANCE) {  // channel sums ride along with the gray pass (no second read of the frames)
+        if ((st = wb_scratch(c)) != HT_OK) return st;
+        HT_HIP(c, hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned long long) * 4 * (size_t)c->nframes, c->stream));
+        c->wb_fused = (c->W & 3) == 0;  // the linear gray kernel carries the sums; odd widths take the separate pass below
+        c->wb_enqueued = true;
+    }
+    st = ht_launch_pyramid(c, flags);
+    c->wb_fused = false;
     if (st != HT_OK) return st;
+    if (c->wb_enqueued && (c->W & 3) != 0 && (st = ht_launch_whitebalance(c, c->d_scratch, false)) != HT_OK) return st;
     st = ht_launch_scan(c, flags);
     if (st != HT_OK) return st;
     c->enqueued = true;
+    c->enq_nframes = c->nframes;  // ht_detect_collect reports THIS batch even if other frames were bound / swapped in meanwhile
     return HT_OK;
 }
 
@@ -656,7 +716,8 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
     }
     const uint32_t found = c->h_counters.nhits;
     if (total) *total = found;
-    if (counts) std::memset(counts, 0, sizeof(uint32_t) * (size_t)c->nframes);
+    const uint32_t nfr = (uint32_t)c->enq_nframes;
+    if (counts) std::memset(counts, 0, sizeof(uint32_t) * (size_t)nfr);
     if (found > c->hit_capacity)
         return ht_fail(c, HT_ERR_CAPACITY, "ht_detect_collect: more raw hits than ht_config.hit_capacity; results incomplete");
     std::vector<ht_hit> tmp(found);
@@ -669,7 +730,7 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
     }
     if (counts)
         for (uint32_t i = 0; i < found; i++)
-            if (tmp[i].frame < (uint32_t)c->nframes) counts[tmp[i].frame]++;
+            if (tmp[i].frame < nfr) counts[tmp[i].frame]++;
     const uint32_t ncopy = std::min(found, cap);
     if (hits && ncopy) std::memcpy(hits, tmp.data(), (size_t)ncopy * sizeof(ht_hit));
     if (found > cap) return ht_fail(c, HT_ERR_CAPACITY, "ht_detect_collect: caller buffer too small for all hits");
@@ -728,19 +789,8 @@ extern "C" ht_status ht_grayscale_batch(ht_ctx *c, uint8_t *host_rgba, int32_t n
     return st;
 }
 
-extern "C" ht_status ht_whitebalance_batch(ht_ctx *c, double *out, int32_t n) {
-    if (!c || !out) return HT_ERR_INVALID;
-    if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_whitebalance_batch: no frames bound");
-    HT_HIP(c, hipSetDevice(c->device));
-    const size_t need = sizeof(unsigned long long) * 4 * (size_t)c->max_batch;
-    if (c->d_scratch_bytes < need) {
-        if (c->d_scratch) (void)hipFree(c->d_scratch);
-        c->d_scratch = nullptr;
-        HT_HIP(c, hipMalloc(&c->d_scratch, need));
-        c->d_scratch_bytes = need;
-    }
-    ht_status st = ht_launch_whitebalance(c, c->d_scratch);
-    if (st != HT_OK) return st;
+// per-frame channel sums on the device -> getWhitebalance values (whitebalance.js:14-26)
+static ht_status wb_finish(ht_ctx *c, double *out, int32_t n) {
     std::vector<unsigned long long> sums((size_t)n * 4);
     HT_HIP(c, hipMemcpyAsync(sums.data(), c->d_scratch, sizeof(unsigned long long) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
     HT_HIP(c, hipStreamSynchronize(c->stream));
@@ -751,6 +801,25 @@ extern "C" ht_status ht_whitebalance_batch(ht_ctx *c, double *out, int32_t n) {
         out[i] = (avgr + avgg + avgb) / 3;  // whitebalance.js:23-26
     }
     return HT_OK;
+}
+
+extern "C" ht_status ht_whitebalance_batch(ht_ctx *c, double *out, int32_t n) {
+    if (!c || !out) return HT_ERR_INVALID;
+    if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_whitebalance_batch: no frames bound");
+    HT_HIP(c, hipSetDevice(c->device));
+    ht_status st = wb_scratch(c);
+    if (st != HT_OK) return st;
+    if ((st = ht_launch_whitebalance(c, c->d_scratch, true)) != HT_OK) return st;
+    c->wb_enqueued = false;  // the scratch sums now belong to this call
+    return wb_finish(c, out, n);
+}
+
+extern "C" ht_status ht_detect_whitebalance(ht_ctx *c, double *out, int32_t n) {
+    if (!c || !out) return HT_ERR_INVALID;
+    if (!c->wb_enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_whitebalance: the last ht_detect_enqueue did not carry HT_DETECT_WHITEBALANCE");
+    if (n <= 0 || n > c->enq_nframes) return ht_fail(c, HT_ERR_INVALID, "ht_detect_whitebalance: n exceeds the enqueued batch");
+    HT_HIP(c, hipSetDevice(c->device));
+    return wb_finish(c, out, n);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -145,10 +145,12 @@ struct HtCounters {
 };
 
 // camshift per-stream device state (camshift.js:153-160)
-struct HtCsState {
+struct alignas(16) HtCsState {
     uint32_t model[4096];  // _modelHist
     int32_t sw[4];         // _searchWindow
     double x, y, width, height, angle;  // _trackObj
+    unsigned long long win_px;          // measurement: pixels visited by the window moment passes since the last reset
+    unsigned long long calls;           // measurement: track() calls since the last reset
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -179,6 +181,7 @@ struct ht_ctx {
     bool builtin_cascade = false;  // blob == the cascade ht_cascade_gen.inc was generated from
     uint32_t deep_bias = 1;        // tile kernel hands survivors to the deep kernel when n*bias*ceil(count/64) <= count
                                    // (measured on C2/C4: split 8 + bias 0..1 is the optimum, profiles/r01_sweeps.txt)
+    int dbg_stop_stage = -1, dbg_force_exact = 0, dbg_deep_v = 4, deep_grid = 512;  // HT_DEBUG_* knobs, read once in ht_create
     HtDevStage *d_stages = nullptr;
     uint32_t split_stage = 4;  // stages [0, split) in the tile kernel, [split, nstages) in the deep kernel
 
@@ -217,6 +220,7 @@ struct ht_ctx {
     const uint8_t *d_frames = nullptr;
     size_t frame_stride = 0;
     int nframes = 0;
+    int enq_nframes = 0;  // frames of the batch enqueued last (what ht_detect_collect reports on)
 
     // scan outputs
     uint32_t hit_capacity = 1u << 20, queue_capacity = 0, queue_capacity_cfg = 0;
@@ -233,12 +237,17 @@ struct ht_ctx {
     // whitebalance / grayscale scratch
     double *d_scratch = nullptr;
     size_t d_scratch_bytes = 0;
+    bool wb_fused = false;     // set around ht_launch_pyramid: the gray kernel also accumulates the channel sums into d_scratch
+    bool wb_enqueued = false;  // the last ht_detect_enqueue carried HT_DETECT_WHITEBALANCE (ht_detect_whitebalance may be called)
 
     // camshift
     int cs_streams = 0;
     HtCsState *d_cs = nullptr;
     uint32_t *d_cs_hist = nullptr;  // per-stream current-frame histogram (4096 bins)
     ht_cs_trackobj *d_cs_out = nullptr;
+    ht_cs_trackobj *d_cs_seq_out = nullptr;  // ht_camshift_track_sequence: [calls][streams] results, one D2H at the end
+    size_t cs_seq_cap = 0;
+    int cs_last_first = 0, cs_last_n = 0, cs_last_chunks = 0;  // layout of d_cs_hist after the last track call (debug read-back)
 
     // profiling
     bool profiling = false;
@@ -271,4 +280,4 @@ ht_status ht_scan_plan_tiles(ht_ctx *ctx);
 bool ht_scan_is_builtin_cascade(const uint8_t *blob, size_t len);  // ht_scan.hip
 ht_status ht_scan_pack_deep(ht_ctx *ctx);                           // ht_scan.hip: LDS-resident table for stages >= split_stage                  // ht_scan.hip: per-scale tiling for the geometry
 ht_status ht_launch_gray_inplace(ht_ctx *ctx, uint8_t *d_rgba, int n, size_t stride);  // ht_pyramid.hip
-ht_status ht_launch_whitebalance(ht_ctx *ctx, double *d_out);                            // ht_pyramid.hip
+ht_status ht_launch_whitebalance(ht_ctx *ctx, double *d_out, bool zero);                 // ht_pyramid.hip

@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -39,14 +40,37 @@ napi_value throw_ht(napi_env env, ht_ctx *ctx, ht_status st, const char *where) 
     return nullptr;
 }
 
-bool get_ctx(napi_env env, napi_value v, ht_ctx **out) {
+// What the JS side holds (a napi external): the context plus the lock that serialises every use of it.  An ht_ctx is not
+// thread-safe (include/headtrackr_hip.h) but detectAsync() runs on a libuv pool thread while the JS thread may call any
+// synchronous entry point on the same cached context (headtrackr.js shares one context per cascade): every entry point
+// takes `mu` for the duration of its C-ABI calls, so overlapping calls run one after the other, in lock-acquisition order.
+struct Slot {
+    ht_ctx *ctx = nullptr;
+    std::mutex mu;
+};
+
+bool get_slot(napi_env env, napi_value v, Slot **out) {
     void *p = nullptr;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
         napi_throw_type_error(env, nullptr, "expected a headtrackr_hip context");
         return false;
     }
-    *out = *static_cast<ht_ctx **>(p);
-    if (!*out) {
+    *out = static_cast<Slot *>(p);
+    return true;
+}
+
+// Locks the slot and yields its context; throws (and returns false) when the context was destroyed.
+struct Locked {
+    std::unique_lock<std::mutex> lk;
+    ht_ctx *ctx = nullptr;
+};
+bool lock_ctx(napi_env env, napi_value v, Locked *out) {
+    Slot *s = nullptr;
+    if (!get_slot(env, v, &s)) return false;
+    out->lk = std::unique_lock<std::mutex>(s->mu);
+    out->ctx = s->ctx;
+    if (!out->ctx) {
+        out->lk.unlock();
         napi_throw_error(env, nullptr, "context was destroyed");
         return false;
     }
@@ -81,8 +105,8 @@ bool get_bytes(napi_env env, napi_value v, uint8_t **data, size_t *len) {
 }
 
 void finalize_ctx(napi_env, void *data, void *) {
-    ht_ctx **slot = static_cast<ht_ctx **>(data);
-    if (*slot) ht_destroy(*slot);
+    Slot *slot = static_cast<Slot *>(data);
+    if (slot->ctx) ht_destroy(slot->ctx);
     delete slot;
 }
 
@@ -123,7 +147,8 @@ napi_value CreateContext(napi_env env, napi_callback_info info) {
     ht_ctx *ctx = nullptr;
     ht_status st = ht_create(&cfg, blob, blob_len, &ctx);
     if (st != HT_OK) return throw_ht(env, nullptr, st, "ht_create");
-    ht_ctx **slot = new ht_ctx *(ctx);
+    Slot *slot = new Slot();
+    slot->ctx = ctx;
     napi_value ext;
     NAPI_OK(napi_create_external(env, slot, finalize_ctx, nullptr, &ext));
     return ext;
@@ -135,9 +160,10 @@ napi_value Destroy(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *p = nullptr;
     if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
-        ht_ctx **slot = static_cast<ht_ctx **>(p);
-        if (*slot) ht_destroy(*slot);
-        *slot = nullptr;
+        Slot *slot = static_cast<Slot *>(p);
+        std::lock_guard<std::mutex> lk(slot->mu);  // waits for an asynchronous job in flight on this context
+        if (slot->ctx) ht_destroy(slot->ctx);
+        slot->ctx = nullptr;
     }
     return nullptr;
 }
@@ -146,8 +172,9 @@ napi_value SetGeometry(napi_env env, napi_callback_info info) {
     size_t argc = 5;
     napi_value argv[5];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    ht_ctx *ctx;
-    if (!get_ctx(env, argv[0], &ctx)) return nullptr;
+    Locked L;
+    if (!lock_ctx(env, argv[0], &L)) return nullptr;
+    ht_ctx *ctx = L.ctx;
     int32_t w, h, nb;
     if (!get_i32(env, argv[1], &w) || !get_i32(env, argv[2], &h) || !get_i32(env, argv[3], &nb)) {
         napi_throw_type_error(env, nullptr, "setGeometry(ctx, w, h, maxBatch, levelDims)");
@@ -178,7 +205,7 @@ napi_value SetGeometry(napi_env env, napi_callback_info info) {
 // ---- detect ----------------------------------------------------------------------------------------------------
 
 struct DetectJob {
-    ht_ctx *ctx = nullptr;
+    Slot *slot = nullptr;
     uint8_t *rgba = nullptr;
     int32_t n = 0, w = 0, h = 0;
     uint32_t flags = 0;
@@ -190,21 +217,29 @@ struct DetectJob {
     napi_async_work work = nullptr;
     napi_deferred deferred = nullptr;
     napi_ref rgba_ref = nullptr;
+    napi_ref ctx_ref = nullptr;  // keeps the context external (and so the Slot) alive until the job completed
 };
 
 void run_detect(DetectJob *j) {
+    std::lock_guard<std::mutex> lk(j->slot->mu);
+    ht_ctx *ctx = j->slot->ctx;
+    if (!ctx) {
+        j->st = HT_ERR_STATE;
+        j->err = "context was destroyed";
+        return;
+    }
     uint32_t cap = 4096;
     for (int attempt = 0; attempt < 3; attempt++) {
         j->hits.resize(cap);
         j->counts.assign((size_t)j->n, 0);
-        j->st = ht_detect_batch(j->ctx, j->rgba, j->n, j->w, j->h, (size_t)j->w * j->h * 4, j->flags, j->hits.data(), cap, j->counts.data(), &j->total);
+        j->st = ht_detect_batch(ctx, j->rgba, j->n, j->w, j->h, (size_t)j->w * j->h * 4, j->flags, j->hits.data(), cap, j->counts.data(), &j->total);
         if (j->st == HT_ERR_CAPACITY && j->total > cap) {  // caller buffer too small: retry with the exact size
             cap = j->total;
             continue;
         }
         break;
     }
-    if (j->st != HT_OK) j->err = ht_last_error(j->ctx);
+    if (j->st != HT_OK) j->err = ht_last_error(ctx);
 }
 
 napi_value pack_hits(napi_env env, const DetectJob &j) {
@@ -242,14 +277,15 @@ napi_value pack_hits(napi_env env, const DetectJob &j) {
     return obj;
 }
 
-bool parse_detect_args(napi_env env, napi_callback_info info, DetectJob *j, napi_value *rgba_val) {
+bool parse_detect_args(napi_env env, napi_callback_info info, DetectJob *j, napi_value *rgba_val, napi_value *ctx_val = nullptr) {
     size_t argc = 6;
     napi_value argv[6];
     if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) != napi_ok || argc < 5) {
         napi_throw_type_error(env, nullptr, "detect(ctx, rgba, n, w, h, flags)");
         return false;
     }
-    if (!get_ctx(env, argv[0], &j->ctx)) return false;
+    if (!get_slot(env, argv[0], &j->slot)) return false;
+    if (ctx_val) *ctx_val = argv[0];
     size_t len = 0;
     int32_t fl = 0;
     if (!get_bytes(env, argv[1], &j->rgba, &len) || !get_i32(env, argv[2], &j->n) || !get_i32(env, argv[3], &j->w) || !get_i32(env, argv[4], &j->h)) {
@@ -270,7 +306,10 @@ napi_value Detect(napi_env env, napi_callback_info info) {
     DetectJob j;
     if (!parse_detect_args(env, info, &j, nullptr)) return nullptr;
     run_detect(&j);
-    if (j.st != HT_OK) return throw_ht(env, j.ctx, j.st, "ht_detect_batch");
+    if (j.st != HT_OK) {
+        napi_throw_error(env, nullptr, ("ht_detect_batch: status " + std::to_string(j.st) + ": " + j.err).c_str());
+        return nullptr;
+    }
     return pack_hits(env, j);
 }
 
@@ -289,20 +328,22 @@ void detect_complete(napi_env env, napi_status, void *data) {
         napi_reject_deferred(env, j->deferred, err);
     }
     napi_delete_reference(env, j->rgba_ref);
+    napi_delete_reference(env, j->ctx_ref);
     napi_delete_async_work(env, j->work);
     delete j;
 }
 
 napi_value DetectAsync(napi_env env, napi_callback_info info) {
     DetectJob *j = new DetectJob();
-    napi_value rgba_val;
-    if (!parse_detect_args(env, info, j, &rgba_val)) {
+    napi_value rgba_val, ctx_val;
+    if (!parse_detect_args(env, info, j, &rgba_val, &ctx_val)) {
         delete j;
         return nullptr;
     }
     napi_value promise, name;
     NAPI_OK(napi_create_promise(env, &j->deferred, &promise));
     NAPI_OK(napi_create_reference(env, rgba_val, 1, &j->rgba_ref));  // keep the frame buffer alive while the GPU works
+    NAPI_OK(napi_create_reference(env, ctx_val, 1, &j->ctx_ref));
     NAPI_OK(napi_create_string_utf8(env, "headtrackr_hip.detect", NAPI_AUTO_LENGTH, &name));
     NAPI_OK(napi_create_async_work(env, nullptr, name, detect_execute, detect_complete, j, &j->work));
     NAPI_OK(napi_queue_async_work(env, j->work));
@@ -312,6 +353,7 @@ napi_value DetectAsync(napi_env env, napi_callback_info info) {
 // ---- grayscale / whitebalance -------------------------------------------------------------------------------------
 
 struct FrameArgs {
+    Locked L;  // the context stays locked for the lifetime of the argument block = the whole entry point
     ht_ctx *ctx;
     uint8_t *rgba;
     int32_t n, w, h;
@@ -319,7 +361,8 @@ struct FrameArgs {
 
 bool parse_frames(napi_env env, napi_value *argv, FrameArgs *a) {
     size_t len = 0;
-    if (!get_ctx(env, argv[0], &a->ctx)) return false;
+    if (!lock_ctx(env, argv[0], &a->L)) return false;
+    a->ctx = a->L.ctx;
     if (!get_bytes(env, argv[1], &a->rgba, &len) || !get_i32(env, argv[2], &a->n) || !get_i32(env, argv[3], &a->w) || !get_i32(env, argv[4], &a->h) ||
         a->n <= 0 || a->w <= 0 || a->h <= 0 || len < (size_t)a->n * a->w * a->h * 4) {
         napi_throw_type_error(env, nullptr, "expected (ctx, Uint8Array rgba, n, w, h, ...) with rgba.length >= n*w*h*4");
@@ -368,9 +411,10 @@ napi_value CamshiftReserve(napi_env env, napi_callback_info info) {
     size_t argc = 2;
     napi_value argv[2];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    ht_ctx *ctx;
+    Locked L;
     int32_t n;
-    if (!get_ctx(env, argv[0], &ctx)) return nullptr;
+    if (!lock_ctx(env, argv[0], &L)) return nullptr;
+    ht_ctx *ctx = L.ctx;
     if (!get_i32(env, argv[1], &n)) {
         napi_throw_type_error(env, nullptr, "camshiftReserve(ctx, nstreams)");
         return nullptr;
@@ -438,8 +482,9 @@ napi_value Info(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    ht_ctx *ctx;
-    if (!get_ctx(env, argv[0], &ctx)) return nullptr;
+    Locked L;
+    if (!lock_ctx(env, argv[0], &L)) return nullptr;
+    ht_ctx *ctx = L.ctx;
     napi_value obj, v;
     NAPI_OK(napi_create_object(env, &obj));
     NAPI_OK(napi_create_int32(env, ht_num_levels(ctx), &v));

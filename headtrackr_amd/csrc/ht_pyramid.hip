@@ -39,14 +39,19 @@ __device__ __forceinline__ uint32_t gray_of(uint32_t px) {  // ccv.js:29
 
 // RGBA -> planar gray (level 0).  ALIGNED: W % 4 == 0, so plane and frame are both linear and 16-byte aligned per
 // group of 4 pixels: one dwordx4 load + one dword store per thread, fully coalesced.
-template <bool GRAY_IN_R>
+// WB: the same pass also accumulates the frame's R, G, B channel sums for headtrackr.getWhitebalance (whitebalance.js:5-30) —
+// the pixels are in registers anyway, so facetrackr's white-balance figure costs no second read of the frame.
+// Exact: integer sums (u32 per thread and per wavefront, u64 per frame), any order gives the reference's value.
+template <bool GRAY_IN_R, bool WB>
 __global__ __launch_bounds__(256) void k_gray_linear(const uint8_t *__restrict__ frames, size_t frame_stride,
                                                      uint8_t *__restrict__ arena, uint64_t arena_stride, uint32_t off0,
-                                                     uint32_t ngroups, uint32_t blocks_per_frame, uint32_t nframes) {
+                                                     uint32_t ngroups, uint32_t blocks_per_frame, uint32_t nframes,
+                                                     unsigned long long *__restrict__ wb_sums) {
     uint32_t f, blk;
     if (!xcd_item(blocks_per_frame, nframes, &f, &blk)) return;
     const uint4 *src = reinterpret_cast<const uint4 *>(frames + (size_t)f * frame_stride);
     uint32_t *dst = reinterpret_cast<uint32_t *>(arena + (uint64_t)f * arena_stride + off0);
+    uint32_t sr = 0, sg = 0, sb = 0;
     for (uint32_t g = blk * blockDim.x + threadIdx.x; g < ngroups; g += blocks_per_frame * blockDim.x) {
         const uint4 p = src[g];
         uint32_t o;
@@ -55,6 +60,29 @@ __global__ __launch_bounds__(256) void k_gray_linear(const uint8_t *__restrict__
         else
             o = gray_of(p.x) | (gray_of(p.y) << 8) | (gray_of(p.z) << 16) | (gray_of(p.w) << 24);
         dst[g] = o;
+        if (WB) {
+            // two channels per add: R and B sit in bits 0-7 / 16-23 of a pixel, so (px & 0x00ff00ff) summed over 4 pixels
+            // cannot carry between the halves (4 * 255 < 2^16)
+            const uint32_t rb = (p.x & 0x00ff00ffu) + (p.y & 0x00ff00ffu) + (p.z & 0x00ff00ffu) + (p.w & 0x00ff00ffu);
+            sr += rb & 0xffffu;
+            sb += rb >> 16;
+            sg += ((p.x >> 8) & 0xffu) + ((p.y >> 8) & 0xffu) + ((p.z >> 8) & 0xffu) + ((p.w >> 8) & 0xffu);
+        }
+    }
+    if (WB) {
+        __shared__ uint32_t s_part[4][3];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            sr += __shfl_xor(sr, s, 64);
+            sg += __shfl_xor(sg, s, 64);
+            sb += __shfl_xor(sb, s, 64);
+        }
+        if ((threadIdx.x & 63u) == 0) s_part[threadIdx.x >> 6][0] = sr, s_part[threadIdx.x >> 6][1] = sg, s_part[threadIdx.x >> 6][2] = sb;
+        __syncthreads();
+        if (threadIdx.x < 3) {  // one 64-bit atomic per channel and workgroup
+            const unsigned long long v = (unsigned long long)s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x];
+            atomicAdd(&wb_sums[(size_t)f * 4 + threadIdx.x], v);
+        }
     }
 }
 
@@ -404,12 +432,18 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
             const uint32_t ngroups = (uint32_t)((size_t)c->W * c->H / 4);
             const uint32_t bpf = std::min<uint32_t>((ngroups + 255) / 256, 2048);
             dim3 grid((bpf * (uint32_t)c->nframes + 7u) & ~7u);
-            if (gray_in_r)
-                hipLaunchKernelGGL(k_gray_linear<true>, grid, dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena,
-                                   c->arena_stride, L0.off[0], ngroups, bpf, (uint32_t)c->nframes);
-            else
-                hipLaunchKernelGGL(k_gray_linear<false>, grid, dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena,
-                                   c->arena_stride, L0.off[0], ngroups, bpf, (uint32_t)c->nframes);
+            unsigned long long *wb = c->wb_fused ? reinterpret_cast<unsigned long long *>(c->d_scratch) : nullptr;
+#define HT_GRAY_LAUNCH(G, W_)                                                                                                          \
+    hipLaunchKernelGGL((k_gray_linear<G, W_>), grid, dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->d_arena, c->arena_stride, \
+                       L0.off[0], ngroups, bpf, (uint32_t)c->nframes, wb)
+            if (gray_in_r) {
+                if (wb) HT_GRAY_LAUNCH(true, true);
+                else HT_GRAY_LAUNCH(true, false);
+            } else {
+                if (wb) HT_GRAY_LAUNCH(false, true);
+                else HT_GRAY_LAUNCH(false, false);
+            }
+#undef HT_GRAY_LAUNCH
         } else {
             dim3 grid((L0.stride / 4 + 63) / 64, (c->H + 3) / 4, c->nframes);
             if (gray_in_r)
@@ -454,10 +488,10 @@ ht_status ht_launch_gray_inplace(ht_ctx *c, uint8_t *d_rgba, int n, size_t strid
     return HT_OK;
 }
 
-ht_status ht_launch_whitebalance(ht_ctx *c, double *d_out) {
+ht_status ht_launch_whitebalance(ht_ctx *c, double *d_out, bool zero) {
     HtProfScope ps(c, "whitebalance");
     unsigned long long *out = reinterpret_cast<unsigned long long *>(d_out);
-    HT_HIP(c, hipMemsetAsync(out, 0, sizeof(unsigned long long) * 4 * (size_t)c->nframes, c->stream));
+    if (zero) HT_HIP(c, hipMemsetAsync(out, 0, sizeof(unsigned long long) * 4 * (size_t)c->nframes, c->stream));
     const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
     hipLaunchKernelGGL(k_channel_sums, dim3(std::min<uint32_t>((npix + 1023) / 1024, 256), c->nframes), dim3(256), 0, c->stream,
                        c->d_frames, c->frame_stride, npix, out);

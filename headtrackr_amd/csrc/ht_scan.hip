@@ -1093,12 +1093,9 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     if (total64 > 0x7fffff00ull) return ht_fail(c, HT_ERR_INVALID, "ht_detect: batch too large for one launch");
     const uint32_t total = (uint32_t)total64;
     const bool gen = c->builtin_cascade && !(flags & HT_SCAN_GENERIC);
-    // measurement knobs (never set in production): stop the tile kernel before a stage / tune the hand-off rule
-    const char *dbg_stop = getenv("HT_DEBUG_STOP_STAGE"), *dbg_bias = getenv("HT_DEBUG_DEEP_BIAS");
-    const int stop_stage = dbg_stop ? atoi(dbg_stop) : -1;
-    // test knob: treat every integer stage decision as an exact tie, i.e. always take the sequential-binary64 fallback
-    const int force_exact = getenv("HT_DEBUG_FORCE_EXACT") ? atoi(getenv("HT_DEBUG_FORCE_EXACT")) : 0;
-    if (dbg_bias) c->deep_bias = (uint32_t)atoi(dbg_bias);
+    // measurement knob: stop the tile kernel before a stage; test knob: treat every integer stage decision as an exact tie,
+    // i.e. always take the sequential-binary64 fallback (both read from the environment once, in ht_create)
+    const int stop_stage = c->dbg_stop_stage, force_exact = c->dbg_force_exact;
     {
         HtProfScope ps(c, "scan_tiles");
         if (gen)
@@ -1113,15 +1110,14 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     }
     if (split < (int)c->nstages) {
         HtProfScope ps(c, "scan_deep");
-        const char *dv = getenv("HT_DEBUG_DEEP_V");
-        const int deep_v = dv ? atoi(dv) : 4;
+        const int deep_v = c->dbg_deep_v;
         if (deep_v == 4 && c->packed_count && c->h_stages[split].first >= c->packed_first) {
             const size_t lds = (size_t)c->packed_count * sizeof(HtPackedFeature) + 64 * sizeof(HtDevStage) + (size_t)DEEPL_WAVES * (PATCH_BYTES + 512);
             if (!c->deep_attr_set) {  // per context (= per device): a single-process multi-GPU host has one context per GPU
                 HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_deep_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 c->deep_attr_set = true;
             }
-            hipLaunchKernelGGL(k_scan_deep_lds, dim3(getenv("HT_DEBUG_DEEP_GRID") ? atoi(getenv("HT_DEBUG_DEEP_GRID")) : 512), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
+            hipLaunchKernelGGL(k_scan_deep_lds, dim3((uint32_t)c->deep_grid), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                                c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, force_exact, c->d_queue, c->queue_capacity,
                                c->d_hits, c->hit_capacity, c->d_counters, stats);
         } else

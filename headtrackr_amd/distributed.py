@@ -2,8 +2,11 @@
 per-frame detection records (RCCL over xGMI when the tensors live on GPUs; the same code runs on gloo/CPU tensors in the
 tests).  One process per GPU (torch.distributed); frames are independent, so there is no other collective.
 
-Record layout (float64 x 8 per frame, 64 B): [raw hit count, scale, q, x, y, confidence of the best raw hit, 0, 0]
-— the strict-'>' arg-max of facetrackr.js:157-165 applied to the raw hits.  Payload is KBs: latency-bound.
+Record layout (float64 x 8 per frame, 64 B): the frame's bounding box as facetrackr.Tracker.doVJDetection selects it
+(facetrackr.js:147-175: ccv.detect_objects(..., 5, 1) grouped rects, strict-'>' arg-max of confidence) —
+[x, y, width, height, confidence, neighbors, global frame index, 1.0]; a frame without a detection carries
+neighbors = 0 and confidence = -10000 (facetrackr.js:239); padding rows (ranks holding fewer frames) are all zero.
+Payload is KBs: latency-bound.  (pack_records — the best RAW hit per frame — is kept for hosts that gather before grouping.)
 """
 from __future__ import annotations
 
@@ -42,6 +45,21 @@ def pack_records(hits: np.ndarray, counts: np.ndarray, nframes: int) -> np.ndarr
     rec[nz, 3] = b["x"]
     rec[nz, 4] = b["y"]
     rec[nz, 5] = b["sum"]
+    return rec
+
+
+def pack_best_records(best: np.ndarray, first_frame: int, rows: int | None = None) -> np.ndarray:
+    """ht_best_faces output (one ht_rect per local frame) -> [rows, 8] float64 records; rows >= len(best) pads with zeros."""
+    n = len(best)
+    rec = np.zeros((rows if rows is not None else n, RECORD_F64), dtype=np.float64)
+    rec[:n, 0] = best["x"]
+    rec[:n, 1] = best["y"]
+    rec[:n, 2] = best["width"]
+    rec[:n, 3] = best["height"]
+    rec[:n, 4] = best["confidence"]
+    rec[:n, 5] = best["neighbors"]
+    rec[:n, 6] = first_frame + np.arange(n)
+    rec[:n, 7] = 1.0
     return rec
 
 

@@ -297,13 +297,17 @@ headtrackr.camshift.TrackObj = function () { /* camshift.js:362-378 */
 };
 
 /* every camshift.Tracker owns one device-side stream slot of a shared context */
-const csPool = { ctx: null, next: 0, free: [] };
+const csPool = { ctx: null, next: 0, free: [], reserved: 0 };
 function csSlot() {
   if (!csPool.ctx) csPool.ctx = contextFor(headtrackr.cascade, 5);
   const slot = csPool.free.length ? csPool.free.pop() : csPool.next++;
-  addon().camshiftReserve(csPool.ctx.handle, Math.max(csPool.next, 1));
+  if (csPool.next > csPool.reserved) { /* grow geometrically: a reservation re-allocates and copies every tracker's state */
+    csPool.reserved = Math.max(csPool.next, 2 * csPool.reserved, 4);
+    addon().camshiftReserve(csPool.ctx.handle, csPool.reserved);
+  }
   return slot;
 }
+headtrackr.camshift._pool = csPool; /* exposed for tests */
 
 headtrackr.camshift.Tracker = function (params) { /* camshift.js:148-354 */
   if (params === undefined) params = {};
@@ -376,7 +380,10 @@ headtrackr.camshift.Tracker = function (params) { /* camshift.js:148-354 */
     return img;
   };
 
-  this.release = function () { csPool.free.push(slot); }; /* not in the reference: returns the device slot */
+  /* not in the reference: returns the device slot (idempotent).  facetrackr.Tracker.release() calls it when the facade
+   * replaces a tracker on "redetecting" / stop(), so a long-running feed that loses its face keeps one slot. */
+  let released = false;
+  this.release = function () { if (!released) { released = true; csPool.free.push(slot); } };
 };
 
 /* ---- facetrackr ------------------------------------------------------------------------------------------------------------ */
@@ -409,6 +416,7 @@ headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
 
   this.init = function (inputcanvas) {
     input = inputcanvas;
+    if (cs) cs.release(); /* a second init() reuses nothing of the first (facetrackr.js:61-65 builds a new camshift.Tracker) */
     cs = new headtrackr.camshift.Tracker({ calcAngles: params.calcAngles });
   };
 
@@ -477,6 +485,8 @@ headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
   };
 
   this.getTrackingObject = function () { return current.clone(); };
+
+  this.release = function () { if (cs) { cs.release(); cs = null; } }; /* not in the reference: frees the camshift device slot */
 };
 
 require('./tracker.js')(headtrackr); /* Smoother, headposition, Tracker facade (host post-processing) */

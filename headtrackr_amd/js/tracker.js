@@ -177,6 +177,7 @@ module.exports = function install(headtrackr) {
           if (face.width === 0 || face.height === 0) { /* lost: zero mass in camshift, main.js:230-248 */
             if (params.retryDetection) {
               status('redetecting');
+              facetracker.release(); /* the lost tracker's camshift slot goes back to the pool */
               facetracker = new headtrackr.facetrackr.Tracker({ whitebalancing: false, calcAngles: params.calcAngles, onEvent: params.onEvent });
               facetracker.init(canvas);
               faceFound = false;
@@ -236,6 +237,7 @@ module.exports = function install(headtrackr) {
       if (timer) clearTimeout(timer);
       run = false;
       status('stopped');
+      if (facetracker !== undefined) facetracker.release();
       facetracker = undefined;
       faceFound = false;
       return true;

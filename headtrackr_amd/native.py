@@ -21,6 +21,7 @@ HT_SCAN_NO_SPLIT = 2
 HT_SCAN_SIMPLE = 4
 HT_SCAN_GENERIC = 8
 HT_SCAN_STATS = 16
+HT_DETECT_WHITEBALANCE = 32
 HT_MAX_LEVELS = 96
 
 
@@ -60,8 +61,8 @@ SYMBOLS = [
     "ht_create", "ht_destroy", "ht_last_error", "ht_abi_version", "ht_set_geometry", "ht_num_levels", "ht_plane",
     "ht_windows_per_frame", "ht_pyramid_bytes_per_frame", "ht_upload_frames", "ht_upload_frames_async", "ht_swap_frames", "ht_bind_frames_device", "ht_detect_enqueue",
     "ht_detect_collect", "ht_detect_batch", "ht_pyramid_readback", "ht_stage_counts", "ht_grayscale_batch",
-    "ht_whitebalance_batch", "ht_hits_to_rects", "ht_group_rects", "ht_best_faces", "ht_camshift_reserve", "ht_camshift_init_batch",
-    "ht_camshift_track_batch", "ht_allgather_records", "ht_profile", "ht_kernel_times", "ht_stream", "ht_synchronize",
+    "ht_whitebalance_batch", "ht_detect_whitebalance", "ht_hits_to_rects", "ht_group_rects", "ht_best_faces", "ht_camshift_reserve", "ht_camshift_init_batch",
+    "ht_camshift_track_batch", "ht_camshift_track_sequence", "ht_camshift_stats", "ht_camshift_debug_hist", "ht_allgather_records", "ht_profile", "ht_kernel_times", "ht_stream", "ht_synchronize",
 ]
 
 _lib = None
@@ -127,6 +128,14 @@ def lib():
     L.ht_camshift_init_batch.argtypes = [vp, i32, i32, vp]
     L.ht_camshift_track_batch.restype = i32
     L.ht_camshift_track_batch.argtypes = [vp, i32, i32, i32, vp]
+    L.ht_detect_whitebalance.restype = i32
+    L.ht_detect_whitebalance.argtypes = [vp, vp, i32]
+    L.ht_camshift_track_sequence.restype = i32
+    L.ht_camshift_track_sequence.argtypes = [vp, i32, i32, i32, vp, i32, sz, vp, i32]
+    L.ht_camshift_stats.restype = i32
+    L.ht_camshift_stats.argtypes = [vp, i32, i32, vp, vp, i32]
+    L.ht_camshift_debug_hist.restype = i32
+    L.ht_camshift_debug_hist.argtypes = [vp, i32, vp, vp]
     L.ht_allgather_records.restype = i32
     L.ht_allgather_records.argtypes = [vp, i32, vp, sz]
     L.ht_profile.restype = i32

@@ -46,7 +46,9 @@ enum {
     HT_SCAN_NO_SPLIT = 2,   /* run every cascade stage in the tile kernel (no second "deep" kernel); debugging / A-B */
     HT_SCAN_SIMPLE = 4,     /* one thread per window straight from HBM (slow reference kernel); debugging / A-B */
     HT_SCAN_GENERIC = 8,    /* table-driven stage code even for the built-in cascade (no generated straight-line stages) */
-    HT_SCAN_STATS = 16      /* also count the windows entering every stage (ht_stage_counts); costs a few atomics per workgroup */
+    HT_SCAN_STATS = 16,     /* also count the windows entering every stage (ht_stage_counts); costs a few atomics per workgroup */
+    HT_DETECT_WHITEBALANCE = 32 /* the gray pass also accumulates getWhitebalance's channel sums (whitebalance.js:5-30): the frame is
+                                 * read once for both; fetch the values with ht_detect_whitebalance after ht_detect_collect */
 };
 
 typedef struct ht_config {
@@ -157,6 +159,9 @@ ht_status ht_grayscale_batch(ht_ctx *ctx, uint8_t *host_rgba, int32_t n, int32_t
                              size_t frame_stride);
 /* headtrackr.getWhitebalance (whitebalance.js:5-30) for the bound frames. */
 ht_status ht_whitebalance_batch(ht_ctx *ctx, double *out, int32_t n);
+/* The same values for the first n frames of the batch last enqueued with HT_DETECT_WHITEBALANCE (fused into the gray pass:
+ * facetrackr's white-balance gate, facetrackr.js:79-95, and its detection read the frame once). Call after ht_detect_collect. */
+ht_status ht_detect_whitebalance(ht_ctx *ctx, double *out, int32_t n);
 
 /* ---- host-side post-processing of raw hits (O(n^2) on tens of rects; stays on the CPU by design) ---------- */
 
@@ -180,6 +185,19 @@ ht_status ht_camshift_reserve(ht_ctx *ctx, int32_t nstreams);
 ht_status ht_camshift_init_batch(ht_ctx *ctx, int32_t first, int32_t n, const ht_cs_rect *rects);
 /* track (camshift.js:213-312) for streams [first, first+n) on bound frames [0, n); out[n] (may be NULL: enqueue only). */
 ht_status ht_camshift_track_batch(ht_ctx *ctx, int32_t first, int32_t n, int32_t calc_angles, ht_cs_trackobj *out);
+/* ncalls successive track() calls (camshift.js:213-220 called once per video frame, main.js:168-180) for streams
+ * [first, first+n) in ONE host call: call k uses the n device-resident frames at dev_frames[k] (frame_stride bytes apart;
+ * same geometry as ht_set_geometry).  A stream's calls are sequentially dependent (its search window), so they are
+ * enqueued back to back on the ctx stream with no host round trip in between.  out (may be NULL: enqueue only) receives
+ * the track objects of the LAST call (out_all == 0, n entries) or of every call (out_all != 0, ncalls*n entries, call-major). */
+ht_status ht_camshift_track_sequence(ht_ctx *ctx, int32_t first, int32_t n, int32_t calc_angles, const void *const *dev_frames,
+                                     int32_t ncalls, size_t frame_stride, ht_cs_trackobj *out, int32_t out_all);
+/* Measurement hook (B_track = 4*W*H + 4*sum of window areas): per stream, the pixels read by the window
+ * moment passes (camshift.js:79-120 called from camshift.js:284-306) and the number of track() calls since the last reset. */
+ht_status ht_camshift_stats(ht_ctx *ctx, int32_t first, int32_t n, uint64_t *window_pixels, uint64_t *calls, int32_t reset);
+/* Test hook: one stream's model histogram (camshift.js:206-208) and the full-frame histogram of its last track() call
+ * (camshift.js:268), 4096 bins each (camshift.Histogram, camshift.js:49-72).  Either pointer may be NULL. */
+ht_status ht_camshift_debug_hist(ht_ctx *ctx, int32_t stream, uint32_t *model, uint32_t *current);
 
 /* ---- multi-GPU: fixed-size result records, all-gathered over RCCL/xGMI ------------------------------------ */
 

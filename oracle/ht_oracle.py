@@ -179,3 +179,35 @@ class Camshift:
 
     def track_obj(self):
         return dict(x=self.s.x, y=self.s.y, width=self.s.width, height=self.s.height, angle=self.s.angle)
+
+
+def cs_init(rgba: np.ndarray, x: int, y: int, w: int, h: int, calc_angles: bool = True) -> Camshift:
+    t = Camshift(calc_angles)
+    t.init_tracker(rgba, (x, y, w, h))
+    return t
+
+
+def cs_track(t: Camshift, rgba: np.ndarray):
+    return t.track(rgba)
+
+
+def cs_histograms(t: Camshift, rgba: np.ndarray):
+    """(model histogram of the tracker, full-frame histogram of `rgba`) as camshift.Histogram computes them
+    (camshift.js:49-72): 4096 bins each."""
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    px = rgba.reshape(-1, 4).astype(np.int64)
+    bins = 256 * (px[:, 0] >> 4) + 16 * (px[:, 1] >> 4) + (px[:, 2] >> 4)
+    return np.array(t.s.model, dtype=np.int64), np.bincount(bins, minlength=4096)
+
+
+def best_faces(rgba_frames, cascade_blob, min_neighbors: int = 1) -> np.ndarray:
+    """facetrackr.Tracker.doVJDetection's selection (facetrackr.js:147-175) per frame: grouped rect of highest confidence
+    (strict '>', first wins); no detection -> zeros, confidence -10000, neighbors 0."""
+    out = np.zeros(len(rgba_frames), dtype=RECT_DTYPE)
+    for i, f in enumerate(rgba_frames):
+        g = detect_objects(f, cascade_blob, 5, min_neighbors)
+        out[i]["confidence"] = -10000.0
+        for k in range(len(g)):
+            if k == 0 or g[k]["confidence"] > out[i]["confidence"]:
+                out[i] = g[k]
+    return out

@@ -86,6 +86,7 @@ job.facetrackr.forEach(function (cs) {
     check(near(t.x, call.x, tol) && near(t.y, call.y, tol) && near(t.width, call.width, tols) && near(t.height, call.height, tols), cs.name + ' call ' + i + ': rect');
   });
   check(events.length === g.events.length, cs.name + ': facetrackingEvent count ' + events.length + ' vs ' + g.events.length);
+  ft.release();
 });
 
 /* headtrackr.Tracker facade: one step() per frame == the reference's track() body (facetrackr -> Smoother -> headposition) */
@@ -107,7 +108,26 @@ job.facetrackr.forEach(function (cs) {
     else check(r.head !== null && near(r.head.x, call.head[0], 0.5) && near(r.head.y, call.head[1], 0.5) && near(r.head.z, call.head[2], 2.5), cs.name + ' frame ' + i + ': head ' + JSON.stringify(r.head) + ' vs ' + JSON.stringify(call.head));
   });
   check(near(tr.getFOV(), g.fov, 1.0), cs.name + ': fov');
+  tr.stop(); /* releases the facade's face tracker (and its camshift slot) */
 });
+
+/* device-slot hygiene (not in the reference): 1000 lost-track / redetect cycles of the facade's tracker replacement must not
+ * grow the camshift reservation — every replaced facetrackr.Tracker hands its slot back */
+(function () {
+  const pool = headtrackr.camshift._pool;
+  const canvas = new Canvas(64, 48);
+  let ft = new headtrackr.facetrackr.Tracker({ whitebalancing: false });
+  ft.init(canvas);
+  const reserved0 = pool.reserved, next0 = pool.next;
+  for (let i = 0; i < 1000; i++) {
+    ft.release();
+    ft = new headtrackr.facetrackr.Tracker({ whitebalancing: false });
+    ft.init(canvas);
+  }
+  check(pool.reserved === reserved0 && pool.next === next0, 'camshift slots leaked: reserved ' + reserved0 + ' -> ' + pool.reserved + ', next ' + next0 + ' -> ' + pool.next);
+  ft.release();
+  check(pool.free.length === pool.next, 'every camshift slot is back in the pool after the tests (' + pool.free.length + ' of ' + pool.next + ')');
+})();
 
 /* batch entry point (async): same frames in one call == per-frame results */
 (async function () {

@@ -20,16 +20,11 @@ N_FRAMES, W, H = 7, 160, 120
 
 
 def _records_for(frames, first):
+    """the all-gathered record = the frame's bounding box as facetrackr selects it (grouped rect of highest confidence)"""
     from oracle import ht_oracle as ho
 
-    blob = load_cascade().blob
-    hits, counts = [], []
-    for f in frames:
-        h = ho.detect_raw(f, blob)
-        hits.append(h)
-        counts.append(len(h))
-    allh = np.concatenate(hits) if hits else np.zeros(0, dtype=ho.HIT_DTYPE)
-    return hd.pack_records(allh, np.array(counts), len(frames))
+    best = ho.best_faces(frames, load_cascade().blob, 1)
+    return hd.pack_best_records(best, first)
 
 
 def _worker(rank, world, port, ret):
@@ -45,8 +40,23 @@ def _worker(rank, world, port, ret):
     gathered = hd.allgather_records(torch.from_numpy(rec), world, maxper).numpy()
     merged = hd.unshard(gathered, N_FRAMES, world)
     full = _records_for(frames, 0)
-    ret[rank] = bool(np.array_equal(merged, full)) and float(merged[:, 0].sum()) > 0
+    ret[rank] = (bool(np.array_equal(merged, full)) and int((merged[:, 5] > 0).sum()) >= 2 and
+                 bool(np.array_equal(merged[:, 6], np.arange(N_FRAMES))) and bool(np.all(merged[:, 7] == 1.0)))
     dist.destroy_process_group()
+
+
+def test_pack_best_records_layout():
+    from headtrackr_amd.native import RECT_DTYPE
+
+    best = np.zeros(3, dtype=RECT_DTYPE)
+    best[0] = (10.5, 20.25, 90.0, 90.0, 3.5, 9, 0)
+    best[1] = (0, 0, 0, 0, -10000.0, 0, 0)
+    best[2] = (1, 2, 3, 4, -1.0, 2, 0)
+    rec = hd.pack_best_records(best, first_frame=128, rows=5)
+    assert rec.shape == (5, hd.RECORD_F64)
+    assert rec[0].tolist() == [10.5, 20.25, 90.0, 90.0, 3.5, 9.0, 128.0, 1.0]
+    assert rec[1].tolist() == [0, 0, 0, 0, -10000.0, 0, 129.0, 1.0]
+    assert not rec[3:].any()
 
 
 def test_shard_ranges_cover_everything():

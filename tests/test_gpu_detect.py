@@ -216,7 +216,11 @@ def test_exact_tie_fallback_path(ctx, cascade, deep_v, monkeypatch):
     want, _ = ctx.detect_raw(frames)
     monkeypatch.setenv("HT_DEBUG_FORCE_EXACT", "1")
     monkeypatch.setenv("HT_DEBUG_DEEP_V", deep_v)
-    got, _ = ctx.detect_raw(frames)
+    forced = Context()  # the knobs are read once, in ht_create
+    try:
+        got, _ = forced.detect_raw(frames)
+    finally:
+        forced.close()
     assert len(want) > 20 and got.tobytes() == want.tobytes()
     ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(6)])
     assert_hits_equal(got, ref)

@@ -1,0 +1,222 @@
+"""Parity at the BENCHMARK shapes (BASELINE.json configs C2 / C3 / C4) — every frame / stream against the CPU oracle, not a
+sample — plus the hooks added for them: histogram read-back, the camshift call sequence, the white-balance sums fused into
+the gray pass, and the context's behaviour when a geometry cannot be allocated.  Everything goes through the C ABI."""
+import math
+
+import numpy as np
+import pytest
+
+from headtrackr_amd import synth
+from headtrackr_amd.api import Context, HtError
+from headtrackr_amd.native import HT_DETECT_WHITEBALANCE, HT_SCAN_STATS
+from oracle import ht_oracle as ho
+from test_gpu_camshift import check as cs_check
+from test_gpu_detect import assert_hits_equal, oracle_hits
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c2_batch_every_frame_vs_oracle(cascade):
+    """C2 (256 x 320x240, the bench's own frames): raw hits of EVERY frame == the oracle's, bit for bit, and the best face
+    per frame (grouping + facetrackr's selection, the bench's timed step) == the oracle's."""
+    w, h, n = 320, 240, 256
+    frames = synth.mixed_batch(n, w, h, seed0=1234)
+    c = Context()
+    try:
+        hits, counts = c.detect_raw(frames)
+        ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(n)])
+        assert_hits_equal(hits, ref)
+        assert np.array_equal(counts, np.bincount(ref["frame"], minlength=n))
+        best = c.best_faces(hits, counts, 1)
+        want = ho.best_faces(frames, cascade.blob, 1)
+        for k in ("x", "y", "width", "height", "confidence", "neighbors"):
+            assert np.array_equal(best[k], want[k]), k
+        assert int((best["neighbors"] > 0).sum()) > n // 3 * 0.9
+    finally:
+        c.close()
+
+
+def test_c4_batch_shape_every_frame_vs_oracle(cascade):
+    """C4 per-GPU shape: 128 x 1280x720 built from the 12 unique frames of the bench (tile count, XCD ordering, survivor
+    queue at 129 M windows): every frame's hits and the per-stage window counts == the oracle's."""
+    w, h, n, uniq = 1280, 720, 128, 12
+    base = synth.mixed_batch(uniq, w, h, seed0=1234)
+    frames = base[np.arange(n) % uniq]
+    stage_ref = np.zeros(cascade.count + 1, dtype=np.int64)
+    per_unique = []
+    for u in range(uniq):
+        sp = np.zeros(cascade.count + 1, dtype=np.int64)
+        hits_u = ho.detect_raw(base[u], cascade.blob, stage_pass=sp)
+        per_unique.append(hits_u)
+        stage_ref += sp * len([i for i in range(n) if i % uniq == u])
+    c = Context()
+    try:
+        c.set_geometry(w, h, n)
+        c.upload(frames)
+        c.detect_enqueue(HT_SCAN_STATS)
+        hits, counts = c.detect_collect(cap=1 << 17)
+        assert c.windows_per_frame == 1007428
+        got_stage = c.stage_counts().astype(np.int64)
+        assert np.array_equal(got_stage, stage_ref), (got_stage, stage_ref)
+        starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        assert len(hits) == starts[-1] and len(hits) > 100
+        for i in range(n):
+            got = hits[starts[i] : starts[i + 1]]
+            r = per_unique[i % uniq]
+            assert len(got) == len(r), f"frame {i}"
+            assert np.all(got["frame"] == i)
+            for k in ("scale", "q", "x", "y"):
+                assert np.array_equal(got[k].astype(np.int64), r[k].astype(np.int64)), (i, k)
+            assert np.array_equal(got["sum"].view(np.uint64), r["sum"].view(np.uint64)), f"frame {i}: confidence bits"
+    finally:
+        c.close()
+
+
+def _c3_streams(n, w, h, nv):
+    """the bench's C3 input: one vote-image face per stream, moved by a seeded <= 3 px walk over nv frame versions"""
+    walk = synth.lcg_stream(4242, 2 * nv * n).astype(np.int64) >> 20
+    vers = np.empty((nv, n, h, w, 4), dtype=np.uint8)
+    for f in range(n):
+        s0 = 48 + (f * 7) % 80
+        x, y = 20 + (f * 13) % (w - s0 - 40), 16 + (f * 29) % (h - s0 - 32)
+        for v in range(nv):
+            vers[v, f] = synth.face_frame(w, h, [(x, y, s0)])
+            x += int(walk[2 * (f * nv + v)] % 7) - 3
+            y += int(walk[2 * (f * nv + v) + 1] % 7) - 3
+    return vers
+
+
+def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
+    """C3: 256 streams, detect once, initTracker on the floored best face (facetrackr.js:97-108), then 60 track() calls in ONE
+    ht_camshift_track_sequence: every call of every stream within +-1 px / +-0.5 deg of the oracle, >= 95 % exact."""
+    import torch
+
+    w, h, n, nv, calls = 320, 240, 256, 4, 60
+    vers = _c3_streams(n, w, h, nv)
+    dev = [torch.from_numpy(vers[v]).cuda() for v in range(nv)]
+    c = Context()
+    try:
+        c.set_geometry(w, h, n)
+        c.bind_device(dev[0].data_ptr(), n)
+        c.camshift_reserve(n)
+        c.detect_enqueue(0)
+        hits, counts = c.detect_collect(cap=1 << 17)
+        best = c.best_faces(hits, counts, 1)
+        assert int((best["neighbors"] > 0).sum()) >= 0.9 * n
+        rects = [(math.floor(best["x"][f]), math.floor(best["y"][f]), math.floor(best["width"][f]), math.floor(best["height"][f]))
+                 if best["neighbors"][f] > 0 else (w // 4, h // 4, w // 2, h // 2) for f in range(n)]
+        c.camshift_init(rects)
+        got = c.camshift_track_sequence([dev[(k + 1) % nv].data_ptr() for k in range(calls)], n, calc_angles=True, fetch="all")
+        assert got.shape == (calls, n)
+        stats = []
+        for f in range(n):
+            o = ho.Camshift(True)
+            o.init_tracker(vers[0, f], rects[f])
+            for k in range(calls):
+                sw, to = o.track(vers[(k + 1) % nv, f])
+                cs_check(got[k, f], sw, to, stats)
+        assert len(stats) == n * calls
+        assert sum(stats) >= 0.95 * len(stats), f"only {sum(stats)}/{len(stats)} track() calls matched the oracle exactly"
+        # the sequence call == the same calls issued one by one
+        c.camshift_init(rects)
+        for k in range(3):
+            c.bind_device(dev[(k + 1) % nv].data_ptr(), n)
+            one = c.camshift_track(n, calc_angles=True)
+            assert one.tobytes() == got[k].tobytes(), k
+        px, ncalls = c.camshift_stats(n, reset=True)
+        assert np.all(ncalls == 3) and np.all(px > 0)
+    finally:
+        c.close()
+
+
+def test_camshift_histograms_bin_for_bin():
+    """camshift.Histogram (camshift.js:49-72): the model histogram of initTracker and the full-frame histogram of track(),
+    read back from the device, equal the oracle's in every one of the 4096 bins — incl. a rect reaching outside the frame
+    (transparent black -> bin 0), an odd pixel count, and a frame cut into many chunk histograms."""
+    for (w, h, rect) in [(320, 240, (100, 60, 90, 80)), (321, 243, (-10, -5, 60, 70)), (1280, 720, (1200, 650, 200, 200))]:
+        a = synth.blob_frame(w, h, w // 2, h // 2, w // 6, h // 8, (4, 3, 5), (200, 60, 40), seed=5)
+        b = synth.blob_frame(w, h, w // 2 + 3, h // 2 + 2, w // 6, h // 8, (4, 3, 5), (200, 60, 40), seed=6)
+        c = Context()
+        try:
+            c.set_geometry(w, h, 1)
+            c.camshift_reserve(1)
+            c.upload(a[None])
+            c.camshift_init([rect])
+            c.upload(b[None])
+            c.camshift_track(1, calc_angles=True)
+            model, cur = c.camshift_debug_hist(0)
+            o = ho.cs_init(a, *rect)
+            want_model, want_cur = ho.cs_histograms(o, b)
+            assert np.array_equal(model.astype(np.int64), want_model), (w, h)
+            assert np.array_equal(cur.astype(np.int64), want_cur), (w, h)
+            assert int(model.sum()) == rect[2] * rect[3] and int(cur.sum()) == w * h
+        finally:
+            c.close()
+
+
+@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (1280, 720)])
+def test_whitebalance_fused_into_gray_pass(w, h, cascade):
+    """HT_DETECT_WHITEBALANCE: getWhitebalance's channel sums ride along with the gray pass (or, for widths that are not
+    multiples of 4, a separate pass): same value as the stand-alone entry point and the oracle, detect results unchanged."""
+    frames = synth.mixed_batch(5, w, h, seed0=77)
+    c = Context()
+    try:
+        plain, _ = c.detect_raw(frames)
+        c.detect_enqueue(HT_DETECT_WHITEBALANCE)
+        hits, _ = c.detect_collect()
+        assert hits.tobytes() == plain.tobytes()
+        wb = c.detect_whitebalance()
+        want = np.array([ho.whitebalance(f) for f in frames])
+        assert np.array_equal(wb, want)
+        assert np.array_equal(c.whitebalance(), want)
+        c.detect_enqueue(0)
+        c.detect_collect()
+        with pytest.raises(HtError):
+            c.detect_whitebalance()
+    finally:
+        c.close()
+
+
+def test_failed_geometry_leaves_a_clean_context(cascade):
+    """A geometry that cannot be allocated (arena far beyond the device) must fail with HT_ERR_NOMEM and leave the context
+    without a half-built geometry: the natural 'try a big batch, fall back to a smaller one' then works."""
+    frames = synth.mixed_batch(3, 320, 240, seed0=1234)
+    c = Context()
+    try:
+        want, _ = c.detect_raw(frames)
+        with pytest.raises(HtError) as e:
+            c.set_geometry(1920, 1080, 200000)  # ~2.6 TB of pyramid
+        assert e.value.status == -3
+        with pytest.raises(HtError):
+            c.detect_enqueue(0)  # nothing bound any more
+        c._max_batch = 0
+        got, _ = c.detect_raw(frames)  # smaller batch: re-plans from scratch
+        assert got.tobytes() == want.tobytes()
+        with pytest.raises(HtError) as e:
+            c.set_geometry(320, 240, 3, level_dims=np.full(2 * c.num_levels, 999999, dtype=np.int32))
+        assert e.value.status == -1
+        c.upload(frames)  # bad level_dims are rejected BEFORE the current geometry is torn down
+        c.detect_enqueue(0)
+        got, _ = c.detect_collect()
+        assert got.tobytes() == want.tobytes()
+    finally:
+        c.close()
+
+
+def test_collect_reports_the_enqueued_batch(cascade):
+    """enqueue(A: 4 frames) -> swap in B (2 frames) -> collect: counts[] has A's 4 entries and A's hits"""
+    A = np.ascontiguousarray(synth.mixed_batch(4, 320, 240, seed0=1234))
+    B = np.ascontiguousarray(synth.mixed_batch(2, 320, 240, seed0=4321))
+    c = Context()
+    try:
+        c.set_geometry(320, 240, 4)
+        want, want_counts = c.detect_raw(A)
+        c.upload(A)
+        c.upload_async_ptr(B.ctypes.data, 2)
+        c.detect_enqueue(0)
+        c.swap_frames()
+        c.nframes = 4  # the Python wrapper sizes counts[] by its own idea of the batch; the library must not overrun it
+        got, counts = c.detect_collect()
+        assert got.tobytes() == want.tobytes() and np.array_equal(counts, want_counts)
+    finally:
+        c.close()

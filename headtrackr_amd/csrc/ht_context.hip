@@ -424,7 +424,10 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
                 const int np = passes / nby + (y < passes % nby ? 1 : 0);
                 for (int x = 0; x < nbx; x++) {
                     HtResampleJob t = j;
-                    t.bx = (uint16_t)x, t.pass0 = (uint16_t)pass0, t.np = (uint16_t)np, t.pad = 0;
+                    t.bx = (uint16_t)x, t.pass0 = (uint16_t)pass0, t.np = (uint16_t)np;
+                    // bit 0: exact 2:1 in both directions (2x2 box mean in integers, see rs_pixels4_lds); HT_DEBUG_RS_NOFAST=1 keeps
+                    // every pixel on the declared binary64 sequence (A/B and cross-check)
+                    t.pad = getenv("HT_DEBUG_RS_NOFAST") ? 2 : (uint16_t)((j.dw > 0 && j.sw == 2 * j.dw && j.sh == 2 * j.dh) ? 1 : 0);
                     tiles.push_back(t);
                 }
                 pass0 += np;
@@ -534,6 +537,7 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
     c->enqueued = false;
     const ht_status st = set_geometry_impl(c, width, height, max_batch, level_dims, n, upto);
     if (st != HT_OK) {  // no half-built geometry: the early-out above must not fire on a retry
+        (void)hipGetLastError();  // a failed hipMalloc leaves a sticky error that the next launch check would report
         free_geometry(c);
         c->W = c->H = c->max_batch = c->nlevels = c->upto = 0;
     }

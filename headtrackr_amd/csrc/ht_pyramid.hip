@@ -172,17 +172,75 @@ __device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap (&cx)
 // sum (x * 0 = +0 for every byte x).  The four taps of a pixel are therefore p[0], p[1], p[pitch], p[pitch + 1] from one
 // address (ds_read_u8 with immediate offsets) whatever the clamping; s_src carries one spare row for the p[pitch] read
 // of the last staged row.  Store: round half to even via the 2^52 + 2^51 add (values are within [0, 255]).
-__device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int (&ia)[4], const double (&cu)[4], const double (&ct)[4],
-                                                   double ru, double rt, int npx) {
+// p = address of the left taps, p1 = address of the right taps (= p + 1, but derived from a separately "laundered" index: hipcc
+// otherwise fuses p[0] and p[1] into ONE ds_read_u16 at an arbitrary byte address, and gfx950's LDS serves a misaligned
+// access lane by lane — 64 instead of 2 cycles per wave, measured with tools/micro/lds_unaligned_bench.hip; the first build of
+// the binary32 path ran 2.3x slower than the binary64 one because of it)
+__device__ __forceinline__ uint32_t rs_pixel_f64(const uint8_t *p, const uint8_t *p1, double cu, double ct, double ru, double rt) {
+    const double top = __dadd_rn(__dmul_rn((double)p[0], cu), __dmul_rn((double)p1[0], ct));
+    const double bot = __dadd_rn(__dmul_rn((double)p[RS_SP], cu), __dmul_rn((double)p1[RS_SP], ct));
+    const double vv = __dadd_rn(__dmul_rn(top, ru), __dmul_rn(bot, rt));
+    return (uint32_t)__double2loint(__dadd_rn(vv, 6755399441055744.0));
+}
+
+// The declared value needs binary64 only where it decides something: the stored byte is RNE(v), and v is needed to far
+// less than binary64 precision unless it sits next to a rounding boundary k + 0.5.  So every pixel is first evaluated in
+// binary32 — v~ = top + ty * (bot - top), top = p00 + tx * (p01 - p00), bot likewise, three v_fma_f32 — whose distance from
+// the declared binary64 value is bounded:
+//     tx32 = fl32(tx): |tx32 - tx| <= 2^-25, times |p01 - p00| <= 255                      ->  7.6e-6
+//     every binary32 rounding of a value <= 255.x is <= half an ulp of [128, 256) = 2^-17  ->  7.6e-6 each
+//     top, bot: 2 terms each (1.52e-5); bot - top: their sum + 1 rounding (3.8e-5); times ty <= 1; + ty32's 7.6e-6
+//     + top's 1.52e-5 + the last fma's rounding 7.6e-6                                      =  6.9e-5  < RS_EPS = 2^-13
+// (the declared u = fl64(1 - t) differs from 1 - t by <= 2^-54 and the six binary64 roundings of the declaration by < 2e-13:
+// both vanish in the margin).  If |v~ - rint(v~)| < 0.5 - RS_EPS the declared value lies strictly between the same two
+// boundaries and rounds to the same integer whatever the tie rule; otherwise (2.4e-4 of the pixels of natural images,
+// every exact tie of the declaration among them) that pixel is re-evaluated with the declared binary64 sequence.
+// An exact 2:1 canvas (both source dimensions even: ccv.js:126-128 halves) is a 2x2 box mean, (a+b+c+d)/4 exactly, whose
+// ties (a quarter of all pixels) would all take the fallback: it is computed in integers instead, RNE included.
+constexpr float RS_EPS = 1.0f / 8192.0f;
+
+__device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int (&ia)[4], const int (&ib)[4], const double (&cu)[4], const double (&ct)[4],
+                                                   const float (&ctf)[4], double ru, double rt, float rtf, int npx, uint32_t mode) {
     uint32_t o = 0;
+    if (mode & 2u) {  // HT_DEBUG_RS_NOFAST: the declared binary64 sequence for every pixel (A/B and cross-check)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < npx) o |= rs_pixel_f64(row + ia[k], row + ib[k], cu[k], ct[k], ru, rt) << (8 * k);
+        return o;
+    }
+    if (mode & 1u) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k < npx) {
+                const uint8_t *p = row + ia[k], *p1 = row + ib[k];
+                const uint32_t sum = (uint32_t)p[0] + p1[0] + p[RS_SP] + p1[RS_SP];
+                const uint32_t q = sum >> 2, r = sum & 3u;
+                o |= (q + ((r + (q & 1u)) > 2u ? 1u : 0u)) << (8 * k);  // RNE(sum / 4): up on .75, on .5 only to the even neighbour
+            }
+        }
+        return o;
+    }
+    uint32_t need = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (k < npx) {
-            const uint8_t *p = row + ia[k];
-            const double top = __dadd_rn(__dmul_rn((double)p[0], cu[k]), __dmul_rn((double)p[1], ct[k]));
-            const double bot = __dadd_rn(__dmul_rn((double)p[RS_SP], cu[k]), __dmul_rn((double)p[RS_SP + 1], ct[k]));
-            const double vv = __dadd_rn(__dmul_rn(top, ru), __dmul_rn(bot, rt));
-            o |= (uint32_t)__double2loint(__dadd_rn(vv, 6755399441055744.0)) << (8 * k);
+            const uint8_t *p = row + ia[k], *p1 = row + ib[k];
+            const float p00 = (float)p[0], p01 = (float)p1[0], p10 = (float)p[RS_SP], p11 = (float)p1[RS_SP];
+            const float top = __builtin_fmaf(ctf[k], p01 - p00, p00);
+            const float bot = __builtin_fmaf(ctf[k], p11 - p10, p10);
+            const float v = __builtin_fmaf(rtf, bot - top, top);
+            const float r = __builtin_rintf(v);
+            if (__builtin_fabsf(v - r) >= 0.5f - RS_EPS) need |= 1u << k;
+            o |= (uint32_t)(int)r << (8 * k);
+        }
+    }
+    if (need) {  // rare: the declared binary64 sequence for the pixels next to a rounding boundary
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (need & (1u << k)) {
+                o &= ~(0xffu << (8 * k));
+                o |= rs_pixel_f64(row + ia[k], row + ib[k], cu[k], ct[k], ru, rt) << (8 * k);
+            }
         }
     }
     return o;
@@ -272,13 +330,17 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
         __syncthreads();
         RS_STAMP(1);
-        int ia[4];
+        int ia[4], ib[4];
         double cu[4], ct[4];
+        float ctf[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const RsTap tp = s_col[min(x0 - X0 + k, ncols - 1)];
-            ia[k] = tp.a - xa, cu[k] = tp.u, ct[k] = tp.t;
+            ia[k] = tp.a - xa, cu[k] = tp.u, ct[k] = tp.t, ctf[k] = (float)tp.t;
+            ib[k] = ia[k] + 1;
+            asm volatile("" : "+v"(ib[k]));  // opaque to the optimiser: keeps the left / right taps separate ds_read_u8 (see rs_pixel_f64)
         }
+        const uint32_t mode = J.pad;  // bit 0: 2x2 box mean (both ratios exactly 2), bit 1: binary64 everywhere (set by the host)
         const int dh = J.dh, ch = J.ch, dst_stride = J.dst_stride;  // locals: not re-read from the record after each store
         const uint32_t doff = J.dst_off + (uint32_t)(yt * dst_stride + x0);
         for (uint32_t f = f0; f < f1; f++, frame += arena_stride) {
@@ -302,7 +364,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
                 if (q < np && y < dh && npx > 0) {
                     const RsTap ry = s_row[y - Y0];
                     if (HT_RS_EXPERIMENT == 1) o[q] = *reinterpret_cast<const uint32_t *>(s_src + (ry.a - ya) * RS_SP + (ia[0] & ~3));
-                    else o[q] = rs_pixels4_lds(s_src + (ry.a - ya) * RS_SP, ia, cu, ct, ry.u, ry.t, npx);
+                    else o[q] = rs_pixels4_lds(s_src + (ry.a - ya) * RS_SP, ia, ib, cu, ct, ctf, ry.u, ry.t, (float)ry.t, npx, mode);
                 }
             }
 #ifdef HT_RS_TIMELINE

@@ -45,7 +45,16 @@ constexpr int TYH = HT_TILE_TYH;        // tile height in half-window steps Y'
 #define HT_TILE_NT 256
 #endif
 constexpr int NT = HT_TILE_NT;          // threads per workgroup (256: 4 waves/SIMD at <=128 VGPRs; 512: 8 waves/SIMD at <=64)
-constexpr int PITCH0 = (2 * TXH + 24 + 15) & ~15;  // 160: plane-0 bytes per LDS row (152 needed; a multiple of 16 so rows are staged in 16-byte chunks)
+#ifndef HT_TILE_PITCH
+#define HT_TILE_PITCH 152
+#endif
+// plane-0 bytes per LDS row: 2*TXH + 24 = 152 are needed.  A window's base address steps by 2*PITCH0 bytes per half-step row, i.e.
+// PITCH0/2 dwords: 152 -> 76 = 12 (mod 32 banks), so 8 consecutive rows start in 8 different 4-bank slots (0,12,24,4,16,28,8,20).
+// With 160 the step was 16 (mod 32): rows r and r+2 aliased, and compacted survivors — which cluster in 2-D blobs — hit the
+// same banks from every other row (36 % of the kernel's LDS cycles were bank conflicts; tools/sim_scan_lds.py models
+// 61 % -> 44 % overhead over conflict-free).  Multiple of 8: rows are staged as 16-byte loads split into two 8-byte LDS writes.
+constexpr int PITCH0 = HT_TILE_PITCH;
+static_assert(PITCH0 >= 2 * TXH + 24 && PITCH0 % 8 == 0, "PITCH0");
 constexpr int ROWS0 = 2 * TYH + 22;     // 86
 constexpr int P0_BYTES = PITCH0 * ROWS0;  // 13760
 constexpr int GH = TYH + 11;               // plane-1 / plane-2 half-step grid: 75 x 43 cells of 2 bytes
@@ -53,7 +62,7 @@ constexpr int G_PITCH = 2 * PITCH0;          // 320
 constexpr int P12_BASE = P0_BYTES;
 constexpr int LDS_TILE_BYTES = P0_BYTES + GH * G_PITCH;  // 27520
 constexpr int MAXWIN = TXH * TYH;            // 2048 windows per tile
-static_assert(PITCH0 % 16 == 0 && P0_BYTES % 16 == 0, "alignment");
+static_assert(P0_BYTES % 16 == 0, "alignment");
 
 // unified-base LDS offsets of a feature point (x, y) on plane 0 / 1 / 2, relative to the window base B
 #define HT_O0(x, y) ((y) * PITCH0 + (x))                      // level i:        1 B/px, row pitch P
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         // plane 0: level i, origin (2*X0, 2*Y0), PITCH0 bytes per row
         const uint8_t *p0 = fbase + L0.off[0];
         const int gx0 = 2 * X0, gy0 = 2 * Y0;
-        constexpr int C0 = PITCH0 / 16;
+        constexpr int C0 = (PITCH0 + 15) / 16;  // 16-byte chunks per row; with PITCH0 % 16 == 8 the last one is half a chunk
         const int n0 = (2 * th + 22) * C0;
         constexpr int K0 = (ROWS0 * C0 + NT - 1) / NT;
         uint4 v0[K0];
@@ -213,7 +222,16 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 #pragma unroll
         for (int k = 0; k < K0; k++) {
             const int i = (int)tid + k * NT;
-            if (i < n0) *reinterpret_cast<uint4 *>(&lds[i * 16]) = v0[k];  // rows are contiguous: r*PITCH0 + c16 == i*16
+            if (i < n0) {
+                if (PITCH0 % 16 == 0) {
+                    *reinterpret_cast<uint4 *>(&lds[i * 16]) = v0[k];  // rows are contiguous: r*PITCH0 + c16 == i*16
+                } else {  // rows are 8-byte aligned: two 8-byte halves, the second one dropped where it would spill into the next row
+                    const int r = i / C0, c16 = (i - r * C0) * 16;
+                    uint2 *d = reinterpret_cast<uint2 *>(&lds[r * PITCH0 + c16]);
+                    d[0] = make_uint2(v0[k].x, v0[k].y);
+                    if (c16 + 8 < PITCH0) d[1] = make_uint2(v0[k].z, v0[k].w);
+                }
+            }
         }
 #pragma unroll
         for (int k = 0; k < K12; k++) {
@@ -257,6 +275,8 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 xx[u] = id[u] - __umul24(yy[u], (uint32_t)S.tw2);
                 valid[u] = valid[u] && xx[u] < (uint32_t)tw;
             }
+            // a wavefront whose 64 + 64 windows all lie beyond the tile's last window has nothing to evaluate (wave-uniform branch)
+            if (base + (tid & ~63u) >= n_in) continue;
             ht_gen_stage_0_x2(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), lds + (valid[1] ? 2u * (yy[1] * PITCH0 + xx[1]) : 0u), Fv[0], Fv[1]);
             bool pass[2];
 #pragma unroll
@@ -363,6 +383,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                     const uint32_t yy = __umul24(id[u], S.div_magic) >> 20, xx = id[u] - __umul24(yy, (uint32_t)S.tw2);
                     Bv[u] = 2u * (yy * PITCH0 + xx);
                 }
+                if (base + (tid & ~63u) >= n_in) continue;  // no survivor on this wavefront (after the barrier: every wave hits it)
                 ht_gen_stage_1_x2(lds + (valid[0] ? Bv[0] : 0u), lds + (valid[1] ? Bv[1] : 0u), Fv[0], Fv[1]);
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
@@ -387,6 +408,11 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             uint32_t id = 0;
             if (valid) id = (s == 0) ? pos : (uint32_t)qbuf[cur][qoff + pos];
             if (HT_TILE_INPLACE && s > 0) __syncthreads();  // every entry of this chunk is in a register before survivors overwrite the queue
+            // Survivors are compacted, so the waves behind the last survivor have no valid lane: they skip the stage body
+            // (wave-uniform branch; the barrier above and the one after the loop are still hit by every wave).  With 65..255
+            // survivors — the usual case in stages 2-3 — up to three of the four waves used to walk the whole stage on dead lanes,
+            // 16 % of the kernel's LDS instructions (tools/sim_scan_lds.py).
+            if (base + (tid & ~63u) >= n_in) continue;
             const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
             valid = valid && xx < (uint32_t)tw;
             const uint32_t B = 2u * (yy * PITCH0 + xx);

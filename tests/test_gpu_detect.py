@@ -146,6 +146,36 @@ def test_gray_in_r_entry(ctx, cascade):
     assert len(a) == 9 and a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (1280, 720)])
+def test_pyramid_fast_paths_equal_the_declared_binary64_sequence(w, h, monkeypatch):
+    """k_resample evaluates a pixel in binary32 and falls back to the declared binary64 sequence next to a rounding boundary;
+    exact 2:1 canvases are integer box means.  HT_DEBUG_RS_NOFAST keeps every pixel on the binary64 sequence: all planes of
+    both builds must be identical (and both equal the oracle, test_pyramid_planes_vs_oracle)."""
+    frames = np.stack([synth.noise_frame(w, h, 11), synth.smooth_frame(w, h, 12), synth.face_frame(w, h, [(w // 8, h // 8, min(w, h) // 2)])])
+
+    def planes():
+        c = Context()
+        try:
+            c.set_geometry(w, h, len(frames))
+            c.upload(frames)
+            c.detect_enqueue(HT_INPUT_RGBA)
+            c.detect_collect()
+            out = []
+            for f in range(len(frames)):
+                for i in range(c.num_levels):
+                    for s in range(4):
+                        if c.plane(i, s).present:
+                            out.append(c.pyramid_readback(f, i, s).tobytes())
+            return out
+        finally:
+            c.close()
+
+    fast = planes()
+    monkeypatch.setenv("HT_DEBUG_RS_NOFAST", "1")
+    slow = planes()
+    assert len(fast) == len(slow) == 3 * 120 and fast == slow
+
+
 def test_720p_vs_oracle(ctx, cascade):
     w, h = 1280, 720
     frames = np.stack([synth.smooth_frame(w, h, 77), synth.face_frame(w, h, [(400, 200, 240), (900, 100, 64), (100, 500, 150)])])

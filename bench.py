@@ -400,11 +400,12 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
     px, calls = ctx.camshift_stats(nf, reset=True)
     win_px_per_call = float(px.sum()) / max(float(calls.sum()), 1.0)
     b_track = 4 * W * H + 4 * win_px_per_call  # one full-frame histogram pass + the window passes, per stream and call
-    per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items() if k in ("cs_hist", "cs_meanshift")}
+    # >= 192 streams: ONE kernel per call (k_cs_track_fused: histogram + LUT + mean-shift); fewer: k_cs_hist + k_cs_meanshift
+    per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items() if k in ("cs_hist", "cs_meanshift", "cs_track")}
     dom = max(per_launch, key=per_launch.get)
     call_ms = sum(per_launch.values())
     achieved = b_track * nf / (per_launch[dom] * 1e-3) / 1e9
-    own = {"cs_hist": 4 * W * H * nf, "cs_meanshift": 4 * win_px_per_call * nf}
+    own = {"cs_hist": 4 * W * H * nf, "cs_meanshift": 4 * win_px_per_call * nf, "cs_track": b_track * nf}
     rec = {
         "value": round(total_frames / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "scaling": "weak",
         "config": {"workload": WORKLOAD_TEXT["c3"], "streams_per_gpu": nf, "track_calls_per_step": CALLS, "width": W, "height": H,
@@ -512,7 +513,7 @@ def stream_bench(env, a):
         ach = b_detect / (det[dom] * 1e-3) / 1e9
         win = float(px[0]) / max(float(calls[0]), 1.0)
         b_track = 4 * W * H + 4 * win
-        cs = {k: v for k, v in per_launch.items() if k in ("cs_hist", "cs_meanshift")}
+        cs = {k: v for k, v in per_launch.items() if k in ("cs_hist", "cs_meanshift", "cs_track")}
         cdom = max(cs, key=cs.get)
         cach = b_track / (cs[cdom] * 1e-3) / 1e9
         roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,

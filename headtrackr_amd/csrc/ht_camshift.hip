@@ -28,6 +28,17 @@
 
 namespace {
 
+#ifdef HT_CS_TIMELINE  // measurement build (tools/gpu_cs_timeline.py): shader-clock stamps of a workgroup's phases
+#define CS_STAMP(arr, i)                                                      \
+    do {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        if ((arr) && threadIdx.x == 0 && (i) < 30) (arr)[(i)] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+    } while (0)
+#else
+#define CS_STAMP(arr, i)
+#endif
+
 constexpr int CS_NT = 512;          // threads of the mean-shift workgroup
 constexpr int HIST_NT = 256;
 // Partial histograms per stream: enough chunks to put ~1024 workgroups on the chip (a single 1080p stream gets 127, a
@@ -54,25 +65,42 @@ __device__ __forceinline__ int32_t toint32(double v) {  // ECMAScript ToInt32 (>
     return (int32_t)(uint32_t)m;
 }
 
-// initTracker: one workgroup per stream
-__global__ __launch_bounds__(256) void k_cs_init(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H,
-                                                 const ht_cs_rect *__restrict__ rects, HtCsState *__restrict__ states, int first) {
+// forward declaration: wave-merged LDS histogram update (defined with k_cs_hist below)
+__device__ __forceinline__ void hist_add_wave(uint32_t *h, uint32_t bin, uint32_t count, bool active);
+
+// initTracker: one 1024-thread workgroup per stream; rows of the rect by wavefront, columns by lane (no per-pixel division),
+// 8 independent loads per lane in flight (a 360 x 360 rect of a 1080p feed took 174 us with the one-pixel-at-a-time loop)
+constexpr int INIT_NT = 1024;
+__global__ __launch_bounds__(INIT_NT) void k_cs_init(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H,
+                                                     const ht_cs_rect *__restrict__ rects, HtCsState *__restrict__ states, int first) {
     __shared__ uint32_t h[4096];
     const int s = blockIdx.x;
-    for (int i = threadIdx.x; i < 4096; i += blockDim.x) h[i] = 0;
+    for (int i = threadIdx.x; i < 4096; i += INIT_NT) h[i] = 0;
     __syncthreads();
     const ht_cs_rect r = rects[s];
     const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)s * frame_stride);
-    const long long n = (long long)max(r.width, 0) * (long long)max(r.height, 0);
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const int y = r.y + (int)(i / r.width), x = r.x + (int)(i % r.width);
-        uint32_t b = 0;  // getImageData outside the canvas: transparent black -> bin 0 (camshift.js:206)
-        if (x >= 0 && x < W && y >= 0 && y < H) b = cs_bin(img[(size_t)y * W + x]);
-        atomicAdd(&h[b], 1u);
+    const int rw = max(r.width, 0), rh = max(r.height, 0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NWV = INIT_NT / 64;
+    for (int j0 = wave; j0 - wave < rh; j0 += 8 * NWV) {      // same trip count for every wavefront's lanes (ballots inside)
+        for (int cb = 0; cb < rw; cb += 64) {
+            const int c = cb + lane;
+            uint32_t px[8];
+            bool in[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int y = r.y + j0 + u * NWV, x = r.x + c;
+                in[u] = c < rw && j0 + u * NWV < rh;                                   // inside the rect
+                const bool img_ok = in[u] && x >= 0 && x < W && y >= 0 && y < H;      // inside the canvas
+                px[u] = img_ok ? img[(size_t)y * W + x] : 0u;  // getImageData outside the canvas: transparent black -> bin 0 (camshift.js:206)
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) hist_add_wave(h, cs_bin(px[u]), 1u, in[u]);
+        }
     }
     __syncthreads();
     HtCsState &st = states[first + s];
-    for (int i = threadIdx.x; i < 4096; i += blockDim.x) st.model[i] = h[i];
+    for (int i = threadIdx.x; i < 4096; i += INIT_NT) st.model[i] = h[i];
     if (threadIdx.x == 0) {
         st.sw[0] = r.x, st.sw[1] = r.y, st.sw[2] = r.width, st.sw[3] = r.height;  // camshift.js:209
         st.x = st.y = st.width = st.height = st.angle = 0.0;                         // camshift.js:210
@@ -135,55 +163,249 @@ struct Mom {
     double m00, m10, m01, m11, m20, m02;
 };
 
+// binary64 wave sum with DPP row shifts / row broadcasts: a fixed tree (deterministic), VALU only.  The __shfl_xor tree it
+// replaces is 6 dependent ds_bpermute round trips per value and half — 36 to 72 LDS round trips per moment pass, which was most
+// of a pass's latency on the small windows of C3.  Lanes a shift does not reach read 0 (bound_ctrl) and add +0.0.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, BANK_MASK, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, BANK_MASK, true);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-    return v;
+    double s = v + dpp_f64<0x111, 0xf, 0xf>(v);  // row_shr:1
+    s += dpp_f64<0x112, 0xf, 0xf>(v);            // row_shr:2
+    s += dpp_f64<0x113, 0xf, 0xf>(v);            // row_shr:3
+    s += dpp_f64<0x114, 0xf, 0xe>(s);            // row_shr:4, banks 1-3
+    s += dpp_f64<0x118, 0xf, 0xc>(s);            // row_shr:8, banks 2-3
+    s += dpp_f64<0x142, 0xa, 0xf>(s);            // row_bcast:15 into rows 1, 3
+    s += dpp_f64<0x143, 0xc, 0xf>(s);            // row_bcast:31 into rows 2, 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), 63), __builtin_amdgcn_readlane(__double2loint(s), 63));
 }
 
-// camshift.Moments (camshift.js:79-120) over columns [x, w) x rows [y, h) — w, h are the right / bottom EDGES
-template <bool SECOND>
-__device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, int W, const double *lut, int x, int y, int w, int h,
-                                              double (*red)[CS_NT / 64]) {
+// camshift.Moments (camshift.js:79-120) over columns [x, w) x rows [y, h) — w, h are the right / bottom EDGES.
+// Mapping: lanes along a row (coalesced RGBA reads), wavefront wv takes rows wv, wv + NW, ...; a row's y factor leaves the pixel
+// loop:  rs = sum val, ts = sum vx*val (us = sum vx^2*val) per row, then m00 += rs, m10 += ts, m01 += vy*rs (m11 += vy*ts,
+// m20 += us, m02 += vy^2*rs) — 2 adds + 1 multiply per pixel for the first moments and no integer division.  Same real-number
+// sums as the reference's column-major loop, different rounding order (see header).
+//
+// The pixels of a pass come either from global memory or — REG — from a copy of the neighbourhood of the search window that the
+// workgroup made in LDS (12-bit histogram bin per pixel, CsRegion): measured on C3, a pass over a 90 x 90 window cost 7-10 us
+// when its loads went out to memory (every CU streams its frame for the histogram at the same time, 4 frame versions do not
+// fit the 256 MB Infinity Cache), although it is two rounds of independent loads; from LDS it is a fraction of a microsecond.
+struct CsRegion {
+    const uint16_t *bins;  // [rh][rw] bins, LDS
+    int x0, y0, rw, rh;    // rw == 0: no region cached
+};
+
+template <bool SECOND, int NW, bool REG>
+__device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, int W, const double *lut, const CsRegion &R, int x, int y, int w, int h,
+                                              double (*red)[NW], unsigned long long *fine = nullptr) {
     Mom m = {0, 0, 0, 0, 0, 0};
+    CS_STAMP(fine, 0);
     const int ww = w - x, hh = h - y;
-    if (ww > 0 && hh > 0) {
-        const int n = ww * hh;
-        for (int i = threadIdx.x; i < n; i += CS_NT) {
-            const int j = i / ww, c = i - j * ww;  // row-major walk: coalesced RGBA reads
-            const double val = lut[cs_bin(img[(size_t)(y + j) * W + (x + c)])];
-            const double vx = (double)c, vy = (double)j;
-            m.m00 += val;
-            m.m01 += vy * val;
-            m.m10 += vx * val;
-            if (SECOND) {
-                m.m11 += vx * vy * val;
-                m.m02 += vy * vy * val;
-                m.m20 += vx * vx * val;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // Shader-clock stamps (HT_CS_TIMELINE) of a pass over an 83 x 83 window: pixel loop 9.3 k cycles, wave sums 0.8 k, final sums
+    // 1.4 k, scalar mean-shift logic 0.45 k — the pixel loop was a chain of dependent round trips (bin -> LUT -> add), made
+    // sequential by per-row early exits that kept the compiler from batching the loads.  So: every load of a batch of 8 rows is
+    // unconditional (clamped address, value masked) and issued before the first use, and only as many wavefronts take part as
+    // there are 8-row batches (at least 4 = one per SIMD); the others wait at the barriers with zero partial sums.
+    const int nwa = min(NW, max(4, (hh + 7) >> 3));
+    if (ww > 0 && hh > 0 && wave < nwa) {
+        for (int j0 = wave; j0 < hh; j0 += 8 * nwa) {
+            double rs[8], ts[8], us[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) rs[r] = ts[r] = us[r] = 0.0;
+            for (int cb = 0; cb < ww; cb += 64) {  // cb: wave-uniform chunk base
+                const int c = cb + lane, cc = min(c, ww - 1);
+                uint32_t px[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const int j = min(j0 + r * nwa, hh - 1);  // clamped address, value masked below
+                    if (REG) px[r] = R.bins[(y + j - R.y0) * R.rw + (x + cc - R.x0)];
+                    else px[r] = cs_bin(img[(size_t)(y + j) * W + (x + cc)]);
+                }
+                double val[8];
+#pragma unroll
+                for (int r = 0; r < 8; r++) val[r] = lut[px[r]];
+                const double vx = (double)c;
+                const bool colok = c < ww;
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const double vv = (colok && j0 + r * nwa < hh) ? val[r] : 0.0;
+                    rs[r] += vv;
+                    ts[r] += vx * vv;
+                    if (SECOND) us[r] += vx * vx * vv;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const double vy = (double)(j0 + r * nwa);  // rows past the window have rs = ts = us = 0
+                m.m00 += rs[r];
+                m.m10 += ts[r];
+                m.m01 += vy * rs[r];
+                if (SECOND) {
+                    m.m11 += vy * ts[r];
+                    m.m20 += us[r];
+                    m.m02 += vy * vy * rs[r];
+                }
             }
         }
     }
     double v[6] = {m.m00, m.m10, m.m01, m.m11, m.m20, m.m02};
-    const int nv = SECOND ? 6 : 3;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int nv = SECOND ? 6 : 3;
+    CS_STAMP(fine, 1);
     __syncthreads();  // red[] may still be read from the previous call
+    CS_STAMP(fine, 2);
+#pragma unroll
     for (int k = 0; k < nv; k++) {
-        const double s = wave_sum_f64(v[k]);
+        const double s = wave < nwa ? wave_sum_f64(v[k]) : 0.0;  // wave-uniform branch; idle waves contribute an exact 0
         if (lane == 0) red[k][wave] = s;
     }
+    CS_STAMP(fine, 3);
     __syncthreads();
+    CS_STAMP(fine, 4);
+#pragma unroll
     for (int k = 0; k < nv; k++) {
         double s = 0.0;
-        for (int q = 0; q < CS_NT / 64; q++) s += red[k][q];  // fixed order
+#pragma unroll
+        for (int q = 0; q < NW; q++) s += red[k][q];  // fixed order; all NW loads issue at once
         v[k] = s;
     }
+    CS_STAMP(fine, 5);
     m.m00 = v[0], m.m10 = v[1], m.m01 = v[2], m.m11 = v[3], m.m20 = v[4], m.m02 = v[5];
     return m;
 }
 
+template <bool SECOND, int NW>
+__device__ __forceinline__ Mom window_moments_any(const uint32_t *__restrict__ img, int W, const double *lut, const CsRegion &R, int x, int y, int w, int h,
+                                                  double (*red)[NW], unsigned long long *fine = nullptr) {
+    // workgroup-uniform: the whole window lies inside the cached region (it practically always does: the region is the search
+    // window plus a margin, and a mean-shift step moves the window by a few pixels)
+    if (R.rw > 0 && x >= R.x0 && y >= R.y0 && w <= R.x0 + R.rw && h <= R.y0 + R.rh) return window_moments<SECOND, NW, true>(img, W, lut, R, x, y, w, h, red, fine);
+    return window_moments<SECOND, NW, false>(img, W, lut, R, x, y, w, h, red, fine);
+}
+
+// Copies the neighbourhood of the search window (the window clamped to the frame, grown by as large a margin as `cap` pixels
+// allow, at most 16) into LDS as histogram bins.  All loads are independent: one round of memory latency for the whole region.
+__device__ __forceinline__ CsRegion cs_region_rect(int W, int H, const int *s_sw, uint16_t *bins, int cap) {
+    CsRegion R = {bins, 0, 0, 0, 0};
+    const int x0 = max(s_sw[0], 0), y0 = max(s_sw[1], 0), x1 = min(x0 + s_sw[2], W), y1 = min(y0 + s_sw[3], H);
+    const int w0 = x1 - x0, h0 = y1 - y0;
+    if (w0 <= 0 || h0 <= 0 || (long long)w0 * h0 > cap) return R;
+    int mg = 0;
+    for (int t = 16; t > 0; t >>= 1)  // largest margin <= 16 px that still fits: a mean-shift step moves the window by a few pixels
+        if ((long long)(min(x1 + mg + t, W) - max(x0 - mg - t, 0)) * (min(y1 + mg + t, H) - max(y0 - mg - t, 0)) <= cap && mg + t <= 16) mg += t;
+    R.x0 = max(x0 - mg, 0), R.y0 = max(y0 - mg, 0);
+    R.rw = min(x1 + mg, W) - R.x0, R.rh = min(y1 + mg, H) - R.y0;
+    return R;
+}
+
+template <int NT_>
+__device__ __forceinline__ CsRegion cs_cache_region(const uint32_t *__restrict__ img, int W, int H, const int *s_sw, uint16_t *bins, int cap) {
+    const CsRegion R = cs_region_rect(W, H, s_sw, bins, cap);
+    if (R.rw == 0) return R;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr int NWV = NT_ / 64;
+    for (int j0 = wave; j0 < R.rh; j0 += 8 * NWV) {  // rows by wavefront, columns by lane: no division, 8 independent loads per batch
+        for (int cb = 0; cb < R.rw; cb += 64) {
+            const int c = min(cb + lane, R.rw - 1);
+            uint32_t px[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) px[r] = img[(size_t)(R.y0 + min(j0 + r * NWV, R.rh - 1)) * W + (R.x0 + c)];
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (cb + lane < R.rw && j0 + r * NWV < R.rh) bins[(j0 + r * NWV) * R.rw + cb + lane] = (uint16_t)cs_bin(px[r]);
+        }
+    }
+    return R;  // the caller synchronises the workgroup before the first pass
+}
+
+// meanShift + camShift (camshift.js:222-312) once the weight LUT is in LDS; every thread runs the identical scalar logic,
+// thread 0 writes the state.  NW = wavefronts of the workgroup.
+template <int NW>
+__device__ __forceinline__ void meanshift_body(const uint32_t *__restrict__ img, int W, int H, const double *lut, const CsRegion &R, double (*red)[NW], const int *s_sw,
+                                               HtCsState &st, int calc_angles, int max_it, ht_cs_trackobj *__restrict__ out_s, unsigned long long *stamps = nullptr) {
+    int swx = s_sw[0], swy = s_sw[1];
+    int n_stamp = 4;
+    (void)n_stamp;
+    const int sww = s_sw[2], swh = s_sw[3];
+    int prevx = swx, prevy = swy;  // camshift.js:280-281
+    Mom m = {0, 0, 0, 0, 0, 0};
+    bool have_second = false;
+    int wadx = 0, wady = 0, wadw = 0, wadh = 0;
+    unsigned long long visited = 0;  // window pixels read by the moment passes (SURVEY.md 8d: B_track = 4*W*H + 4*sum(window))
+    for (int it = 0; it < max_it; it++) {  // camshift.js:284-306; max_it = 10 (HT_DEBUG_CS_ITERS: measurement knob, wrong results)
+        wadx = max(swx, 0);
+        wady = max(swy, 0);
+        wadw = min(wadx + sww, W);
+        wadh = min(wady + swh, H);
+        visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
+        if (it == 9) {
+            m = window_moments_any<true, NW>(img, W, lut, R, wadx, wady, wadw, wadh, red);
+            have_second = true;
+        } else {
+            m = window_moments_any<false, NW>(img, W, lut, R, wadx, wady, wadw, wadh, red, (stamps && it == 0) ? stamps + 16 : nullptr);
+        }
+        CS_STAMP(stamps, n_stamp);
+        n_stamp++;
+        if (it == 0) CS_STAMP(stamps, 22);
+        const double inv = 1.0 / m.m00, xc = m.m10 * inv, yc = m.m01 * inv;  // camshift.js:109-111
+        swx += toint32(xc - (double)sww / 2);                                    // camshift.js:295
+        swy += toint32(yc - (double)swh / 2);                                    // camshift.js:296
+        if (it == 0) CS_STAMP(stamps, 23);
+        if (swx == prevx && swy == prevy) {                                      // camshift.js:299-301
+            if (!have_second) {
+                m = window_moments_any<true, NW>(img, W, lut, R, wadx, wady, wadw, wadh, red);
+                visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
+            }
+            have_second = true;
+            break;
+        }
+        prevx = swx;
+        prevy = swy;
+    }
+    CS_STAMP(stamps, n_stamp);
+    if (threadIdx.x != 0) return;
+    swx = max(0, min(swx, W));  // camshift.js:308-309
+    swy = max(0, min(swy, H));
+    const double invM00 = 1.0 / m.m00, xc = m.m10 * invM00, yc = m.m01 * invM00;
+    const double mu20 = m.m20 - m.m10 * xc, mu02 = m.m02 - m.m01 * yc, mu11 = m.m11 - m.m01 * xc;  // camshift.js:116-118
+    const double a = mu20 * invM00, c = mu02 * invM00;  // camshift.js:230-231
+    double width, height, angle;
+    if (calc_angles) {  // camshift.js:233-245
+        const double b = mu11 * invM00, d = a + c;
+        const double e = sqrt((4 * b * b) + ((a - c) * (a - c)));
+        width = (double)(int32_t)((uint32_t)toint32(sqrt((d - e) * 0.5)) << 2);
+        height = (double)(int32_t)((uint32_t)toint32(sqrt((d + e) * 0.5)) << 2);
+        angle = atan2(2 * b, a - c + e);
+        if (angle < 0) angle = angle + 3.141592653589793;
+    } else {  // camshift.js:247-249
+        width = (double)(int32_t)((uint32_t)toint32(sqrt(a)) << 2);
+        height = (double)(int32_t)((uint32_t)toint32(sqrt(c)) << 2);
+        angle = 3.141592653589793 / 2;
+    }
+    double cx = (double)swx + (double)sww / 2, cy = (double)swy + (double)swh / 2;  // camshift.js:253-254 (old window size)
+    cx = cx < (double)W ? cx : (double)W;
+    cy = cy < (double)H ? cy : (double)H;
+    const double tx = floor(cx > 0 ? cx : 0.0), ty = floor(cy > 0 ? cy : 0.0);
+    const int nsww = (int)floor(1.1 * width), nswh = (int)floor(1.1 * height);  // camshift.js:257-258
+    st.sw[0] = swx, st.sw[1] = swy, st.sw[2] = nsww, st.sw[3] = nswh;
+    st.x = tx, st.y = ty, st.width = width, st.height = height, st.angle = angle;
+    st.win_px += visited;
+    st.calls += 1;
+    if (out_s) {
+        ht_cs_trackobj o;
+        o.x = tx, o.y = ty, o.width = width, o.height = height, o.angle = angle;
+        o.sw_x = swx, o.sw_y = swy, o.sw_width = nsww, o.sw_height = nswh;
+        *out_s = o;
+    }
+}
+
 __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H,
                                                         const uint32_t *__restrict__ hist, int nchunks, HtCsState *__restrict__ states,
-                                                        int first, int calc_angles, ht_cs_trackobj *__restrict__ out) {
+                                                        int first, int calc_angles, int max_it, int region_cap, ht_cs_trackobj *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t cs_dyn[];  // [region_cap] u16 bins of the cached search region
     __shared__ double lut[4096];
     __shared__ double red[6][CS_NT / 64];
     __shared__ int s_sw[4];
@@ -215,73 +437,137 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
     }
     if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
     __syncthreads();
-    int swx = s_sw[0], swy = s_sw[1];
-    const int sww = s_sw[2], swh = s_sw[3];
-    int prevx = swx, prevy = swy;  // camshift.js:280-281
-    Mom m = {0, 0, 0, 0, 0, 0};
-    bool have_second = false;
-    int wadx = 0, wady = 0, wadw = 0, wadh = 0;
-    unsigned long long visited = 0;  // window pixels read by the moment passes (SURVEY.md 8d: B_track = 4*W*H + 4*sum(window))
-    for (int it = 0; it < 10; it++) {  // camshift.js:284-306 (every thread runs the identical scalar logic)
-        wadx = max(swx, 0);
-        wady = max(swy, 0);
-        wadw = min(wadx + sww, W);
-        wadh = min(wady + swh, H);
-        visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
-        if (it == 9) {
-            m = window_moments<true>(img, W, lut, wadx, wady, wadw, wadh, red);
-            have_second = true;
-        } else {
-            m = window_moments<false>(img, W, lut, wadx, wady, wadw, wadh, red);
-        }
-        const double inv = 1.0 / m.m00, xc = m.m10 * inv, yc = m.m01 * inv;  // camshift.js:109-111
-        swx += toint32(xc - (double)sww / 2);                                    // camshift.js:295
-        swy += toint32(yc - (double)swh / 2);                                    // camshift.js:296
-        if (swx == prevx && swy == prevy) {                                      // camshift.js:299-301
-            if (!have_second) {
-                m = window_moments<true>(img, W, lut, wadx, wady, wadw, wadh, red);
-                visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
+    const CsRegion R = cs_cache_region<CS_NT>(img, W, H, s_sw, reinterpret_cast<uint16_t *>(cs_dyn), region_cap);
+    __syncthreads();
+    meanshift_body<CS_NT / 64>(img, W, H, lut, R, red, s_sw, st, calc_angles, max_it, out ? out + s : nullptr);
+}
+
+// One launch per track() call when there are enough streams to fill the chip by themselves: ONE 1024-thread workgroup per stream
+// does the full-frame histogram in LDS, turns it into the weight LUT in place (no partial histograms through HBM, no second
+// launch) and runs the mean-shift loop.  Per stream and call the only memory traffic left is the frame itself (4*W*H, then the
+// window passes from L2), the model histogram (16 KB) and the state.
+constexpr int FUSED_NT = 1024;
+constexpr int CS_REGION_CAP = 40960;  // pixels of the cached search region: 80 KB of LDS next to the 32 KB LUT and the 16 KB histogram
+
+__global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H, uint32_t npix,
+                                                            HtCsState *__restrict__ states, int first, int calc_angles, int max_it, int region_cap,
+                                                            ht_cs_trackobj *__restrict__ out, uint32_t *__restrict__ dbg_hist) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t cs_dyn[];  // [region_cap] u16 bins of the cached search region
+    __shared__ double lut[4096];
+    __shared__ uint32_t h[4096];
+    __shared__ double red[6][FUSED_NT / 64];
+    __shared__ int s_sw[4];
+    const int s = blockIdx.x;
+    HtCsState &st = states[first + s];
+    const uint8_t *frame = frames + (size_t)s * frame_stride;
+#ifdef HT_CS_TIMELINE
+    __shared__ unsigned long long s_stamps[32];
+    if (threadIdx.x < 32) s_stamps[threadIdx.x] = 0;
+    unsigned long long *stamps = s_stamps;
+    __syncthreads();
+#else
+    unsigned long long *stamps = nullptr;
+#endif
+    CS_STAMP(stamps, 0);
+    for (int i = threadIdx.x; i < 4096; i += FUSED_NT) h[i] = 0;
+    if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
+    __syncthreads();
+    // the search region (search window + margin) is cached in LDS as histogram bins for the moment passes; when rows are whole
+    // 16-byte groups the histogram pass below stashes it on the way (the frame is read exactly once), otherwise a separate copy
+    // pass after the LUT does (cs_cache_region)
+    uint16_t *const rbins = reinterpret_cast<uint16_t *>(cs_dyn);
+    const int qpr = W >> 2, rpi = qpr > 0 ? FUSED_NT / qpr : 0;  // 16-byte groups per row, rows per sweep of the workgroup
+    const bool rows2d = (W & 3) == 0 && rpi >= 1;
+    CsRegion R = {rbins, 0, 0, 0, 0};
+    if (rows2d) R = cs_region_rect(W, H, s_sw, rbins, region_cap);
+    {  // camshift.Histogram of the whole frame (camshift.js:268), counts merged per thread and per wavefront like k_cs_hist
+        const uint4 *img4 = reinterpret_cast<const uint4 *>(frame);
+        if (rows2d) {
+            // thread = (row within the sweep, 16-byte group of the row): its column never changes, so the region test is two row
+            // compares per load; 8 independent loads per thread in flight
+            const int trow = (int)threadIdx.x / qpr, tq = (int)threadIdx.x - trow * qpr;
+            const bool tact = trow < rpi;
+            const int colx = 4 * tq - R.x0;  // column of the group's first pixel inside the region
+            const bool colhit = R.rw > 0 && colx + 3 >= 0 && colx < R.rw;
+            for (int row0 = trow; row0 - trow < H; row0 += 8 * rpi) {  // same trip count for every thread (ballots inside)
+                uint4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) p[u] = img4[(size_t)min(row0 + u * rpi, H - 1) * qpr + tq];  // clamped address, masked below
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int row = row0 + u * rpi;
+                    const bool on = tact && row < H;
+                    const uint32_t b0 = cs_bin(p[u].x), b1 = cs_bin(p[u].y), b2 = cs_bin(p[u].z), b3 = cs_bin(p[u].w);
+                    const bool flat = (b0 == b1) && (b2 == b3) && (b0 == b2);
+                    hist_add_wave(h, b0, flat ? 4u : 1u, on);
+                    if (on && !flat) {
+                        atomicAdd(&h[b1], 1u);
+                        atomicAdd(&h[b2], 1u);
+                        atomicAdd(&h[b3], 1u);
+                    }
+                    const int ry = row - R.y0;
+                    if (on && colhit && ry >= 0 && ry < R.rh) {
+                        uint16_t *d = rbins + ry * R.rw + colx;
+                        if (colx >= 0) d[0] = (uint16_t)b0;
+                        if (colx + 1 >= 0 && colx + 1 < R.rw) d[1] = (uint16_t)b1;
+                        if (colx + 2 >= 0 && colx + 2 < R.rw) d[2] = (uint16_t)b2;
+                        if (colx + 3 < R.rw) d[3] = (uint16_t)b3;
+                    }
+                }
             }
-            have_second = true;
-            break;
+        } else {
+            const uint32_t nquad = npix / 4;
+            // 8 independent 16-byte loads per thread in flight (128 KB per workgroup): one workgroup has a whole frame to pull
+            for (uint32_t i0 = threadIdx.x; i0 < nquad; i0 += 8 * FUSED_NT) {
+                uint4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) p[u] = img4[min(i0 + u * FUSED_NT, nquad - 1)];  // clamped address, masked below
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const bool on = i0 + u * FUSED_NT < nquad;
+                    const uint32_t b0 = cs_bin(p[u].x), b1 = cs_bin(p[u].y), b2 = cs_bin(p[u].z), b3 = cs_bin(p[u].w);
+                    const bool flat = (b0 == b1) && (b2 == b3) && (b0 == b2);
+                    hist_add_wave(h, b0, flat ? 4u : 1u, on);
+                    if (on && !flat) {
+                        atomicAdd(&h[b1], 1u);
+                        atomicAdd(&h[b2], 1u);
+                        atomicAdd(&h[b3], 1u);
+                    }
+                }
+            }
+            const uint32_t *img1 = reinterpret_cast<const uint32_t *>(frame);
+            for (uint32_t i = nquad * 4 + threadIdx.x; i < npix; i += FUSED_NT) atomicAdd(&h[cs_bin(img1[i])], 1u);  // < 4 pixels
         }
-        prevx = swx;
-        prevy = swy;
     }
-    if (threadIdx.x != 0) return;
-    swx = max(0, min(swx, W));  // camshift.js:308-309
-    swy = max(0, min(swy, H));
-    const double invM00 = 1.0 / m.m00, xc = m.m10 * invM00, yc = m.m01 * invM00;
-    const double mu20 = m.m20 - m.m10 * xc, mu02 = m.m02 - m.m01 * yc, mu11 = m.m11 - m.m01 * xc;  // camshift.js:116-118
-    const double a = mu20 * invM00, c = mu02 * invM00;  // camshift.js:230-231
-    double width, height, angle;
-    if (calc_angles) {  // camshift.js:233-245
-        const double b = mu11 * invM00, d = a + c;
-        const double e = sqrt((4 * b * b) + ((a - c) * (a - c)));
-        width = (double)(int32_t)((uint32_t)toint32(sqrt((d - e) * 0.5)) << 2);
-        height = (double)(int32_t)((uint32_t)toint32(sqrt((d + e) * 0.5)) << 2);
-        angle = atan2(2 * b, a - c + e);
-        if (angle < 0) angle = angle + 3.141592653589793;
-    } else {  // camshift.js:247-249
-        width = (double)(int32_t)((uint32_t)toint32(sqrt(a)) << 2);
-        height = (double)(int32_t)((uint32_t)toint32(sqrt(c)) << 2);
-        angle = 3.141592653589793 / 2;
+    __syncthreads();
+    CS_STAMP(stamps, 1);
+    {  // getWeights, camshift.js:314-330
+        const uint4 *model4 = reinterpret_cast<const uint4 *>(st.model);
+        const int i4 = threadIdx.x;  // 1024 threads x 4 bins
+        const uint4 m = model4[i4];
+        const uint4 cv = reinterpret_cast<const uint4 *>(h)[i4];
+        if (dbg_hist) reinterpret_cast<uint4 *>(dbg_hist + (size_t)s * 4096)[i4] = cv;
+        const uint32_t chv[4] = {cv.x, cv.y, cv.z, cv.w}, mv[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double p = 0.0;
+            if (chv[q] != 0) {
+                p = (double)mv[q] / (double)chv[q];
+                p = p < 1.0 ? p : 1.0;
+            }
+            lut[i4 * 4 + q] = p;
+        }
     }
-    double cx = (double)swx + (double)sww / 2, cy = (double)swy + (double)swh / 2;  // camshift.js:253-254 (old window size)
-    cx = cx < (double)W ? cx : (double)W;
-    cy = cy < (double)H ? cy : (double)H;
-    const double tx = floor(cx > 0 ? cx : 0.0), ty = floor(cy > 0 ? cy : 0.0);
-    const int nsww = (int)floor(1.1 * width), nswh = (int)floor(1.1 * height);  // camshift.js:257-258
-    st.sw[0] = swx, st.sw[1] = swy, st.sw[2] = nsww, st.sw[3] = nswh;
-    st.x = tx, st.y = ty, st.width = width, st.height = height, st.angle = angle;
-    st.win_px += visited;
-    st.calls += 1;
-    if (out) {
-        ht_cs_trackobj o;
-        o.x = tx, o.y = ty, o.width = width, o.height = height, o.angle = angle;
-        o.sw_x = swx, o.sw_y = swy, o.sw_width = nsww, o.sw_height = nswh;
-        out[s] = o;
-    }
+    CS_STAMP(stamps, 2);
+    // the search region: the frame went through this CU a moment ago, but not into any cache that would still hold it
+    if (!rows2d) R = cs_cache_region<FUSED_NT>(reinterpret_cast<const uint32_t *>(frame), W, H, s_sw, rbins, region_cap);
+    __syncthreads();  // LUT and region complete
+    CS_STAMP(stamps, 3);
+    meanshift_body<FUSED_NT / 64>(reinterpret_cast<const uint32_t *>(frame), W, H, lut, R, red, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, stamps);
+#ifdef HT_CS_TIMELINE
+    if (threadIdx.x == 0 && dbg_hist)
+        for (int i = 0; i < 30; i++) reinterpret_cast<unsigned long long *>(dbg_hist + (size_t)s * 4096 + 4032)[i] = s_stamps[i];
+#endif
 }
 
 }  // namespace
@@ -318,7 +604,7 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
     HT_HIP(c, hipMemcpyAsync(d_rects, rects, sizeof(ht_cs_rect) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     {
         HtProfScope ps(c, "cs_init");
-        hipLaunchKernelGGL(k_cs_init, dim3(n), dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, d_rects, c->d_cs, first);
+        hipLaunchKernelGGL(k_cs_init, dim3(n), dim3(INIT_NT), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, d_rects, c->d_cs, first);
         HT_HIP(c, hipGetLastError());
     }
     HT_HIP(c, hipStreamSynchronize(c->stream));  // rects[] is the caller's (pageable) memory
@@ -329,6 +615,21 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
 static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_stride, int32_t first, int32_t n, int32_t calc_angles,
                               ht_cs_trackobj *d_out) {
     const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
+    if (!c->cs_attr_set) {  // the cached search region needs more than the default 64 KB of LDS per workgroup (per context = per device)
+        HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
+        HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_meanshift), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
+        c->cs_attr_set = true;
+    }
+    // enough streams to keep (most of) the 256 CUs busy with one workgroup each: the fused single-launch kernel; fewer streams
+    // (a handful of large feeds): chunk histograms from every CU, then one mean-shift workgroup per stream
+    if (n >= c->cs_fused_min_streams) {
+        HtProfScope ps(c, "cs_track");
+        hipLaunchKernelGGL(k_cs_track_fused, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, frames, frame_stride, c->W, c->H, npix, c->d_cs, first,
+                           calc_angles, c->dbg_cs_iters, c->cs_region_cap, d_out, c->cs_keep_hist ? c->d_cs_hist : nullptr);
+        HT_HIP(c, hipGetLastError());
+        c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;
+        return HT_OK;
+    }
     uint32_t chunk_px, nchunks;
     hist_chunks(npix, hist_max_chunks(c->cs_streams), &chunk_px, &nchunks);  // buffer sized for cs_streams x that many chunks
     {
@@ -338,8 +639,8 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
     }
     {
         HtProfScope ps(c, "cs_meanshift");
-        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), 0, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_hist, (int)nchunks, c->d_cs,
-                           first, calc_angles, d_out);
+        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), (size_t)CS_REGION_CAP * 2, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_hist, (int)nchunks,
+                           c->d_cs, first, calc_angles, c->dbg_cs_iters, c->cs_region_cap, d_out);
         HT_HIP(c, hipGetLastError());
     }
     c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = (int)nchunks;

@@ -238,6 +238,10 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     if (const char *e = getenv("HT_DEBUG_DEEP_BIAS")) c->deep_bias = (uint32_t)atoi(e);
     if (const char *e = getenv("HT_DEBUG_DEEP_V")) c->dbg_deep_v = atoi(e);
     if (const char *e = getenv("HT_DEBUG_DEEP_GRID")) c->deep_grid = std::max(1, atoi(e));
+    if (const char *e = getenv("HT_DEBUG_CS_FUSED_MIN")) c->cs_fused_min_streams = std::max(1, atoi(e));
+    if (getenv("HT_DEBUG_CS_KEEP_HIST")) c->cs_keep_hist = true;
+    if (const char *e = getenv("HT_DEBUG_CS_REGION")) c->cs_region_cap = std::min(40960, std::max(0, atoi(e)));
+    if (const char *e = getenv("HT_DEBUG_CS_ITERS")) c->dbg_cs_iters = std::min(10, std::max(0, atoi(e)));
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
     c->split_stage = std::min<uint32_t>(c->builtin_cascade ? 8u : 4u, c->nstages);

@@ -247,6 +247,11 @@ struct ht_ctx {
     ht_cs_trackobj *d_cs_out = nullptr;
     ht_cs_trackobj *d_cs_seq_out = nullptr;  // ht_camshift_track_sequence: [calls][streams] results, one D2H at the end
     size_t cs_seq_cap = 0;
+    int cs_fused_min_streams = 192;  // >= this many streams per call: k_cs_track_fused (HT_DEBUG_CS_FUSED_MIN)
+    int dbg_cs_iters = 10;            // HT_DEBUG_CS_ITERS: mean-shift iterations at most (camshift.js:284 has 10; anything else = wrong results)
+    bool cs_keep_hist = false;
+    bool cs_attr_set = false;         // > 64 KB dynamic LDS enabled for the camshift kernels on this context's device
+    int cs_region_cap = 40960;        // pixels of the LDS-cached search region (HT_DEBUG_CS_REGION=0 disables it)        // HT_DEBUG_CS_KEEP_HIST: the fused kernel also writes its histogram for ht_camshift_debug_hist
     int cs_last_first = 0, cs_last_n = 0, cs_last_chunks = 0;  // layout of d_cs_hist after the last track call (debug read-back)
 
     // profiling

@@ -18,9 +18,22 @@ CAMSHIFT = load_golden("camshift.json")
 ANGLE_TOL = math.radians(0.5)
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = Context()
+@pytest.fixture(scope="module", params=["chunked", "fused"])
+def ctx(request):
+    """every test of this module runs on both camshift schedules: chunk histograms + one mean-shift workgroup per stream (few
+    streams), and the single-launch kernel that is chosen for >= 192 streams (forced here with HT_DEBUG_CS_FUSED_MIN=1)"""
+    import os
+
+    old = os.environ.get("HT_DEBUG_CS_FUSED_MIN")
+    if request.param == "fused":
+        os.environ["HT_DEBUG_CS_FUSED_MIN"] = "1"
+    else:
+        os.environ["HT_DEBUG_CS_FUSED_MIN"] = "1000000"
+    c = Context()  # the knob is read once, in ht_create
+    if old is None:
+        os.environ.pop("HT_DEBUG_CS_FUSED_MIN", None)
+    else:
+        os.environ["HT_DEBUG_CS_FUSED_MIN"] = old
     yield c
     c.close()
 
@@ -106,7 +119,8 @@ def test_batch_of_streams_vs_oracle(ctx):
 
 
 @pytest.mark.parametrize("w,h,n", [(1920, 1080, 1), (641, 363, 3), (61, 45, 2)], ids=["1080p-1stream", "odd-641x363", "tiny-61x45"])
-def test_frame_sizes_and_chunking(w, h, n):
+@pytest.mark.parametrize("fused", [False, True], ids=["chunked", "fused"])
+def test_frame_sizes_and_chunking(w, h, n, fused, monkeypatch):
     """The histogram pass cuts a frame into chunk histograms (127 for one 1080p stream, 1 for a tiny frame) and handles
     pixel counts that are not multiples of 4; the mean-shift kernel adds the chunks.  Same answers as the oracle."""
     steps = 4
@@ -116,6 +130,7 @@ def test_frame_sizes_and_chunking(w, h, n):
         cx, cy = w // 2 + 3 * s, h // 2 - 2 * s
         seqs.append([synth.blob_frame(w, h, cx + k, cy + k // 2, a, b, (4, 3, 5), (200, 60, 40), seed=77 + 13 * s + k) for k in range(steps)])
         rects.append((cx - a, cy - b, 2 * a, 2 * b))
+    monkeypatch.setenv("HT_DEBUG_CS_FUSED_MIN", "1" if fused else "1000000")
     c = Context()
     try:
         c.set_geometry(w, h, n)

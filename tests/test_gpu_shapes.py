@@ -89,15 +89,15 @@ def _c3_streams(n, w, h, nv):
 def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
     """C3: 256 streams, detect once, initTracker on the floored best face (facetrackr.js:97-108), then 60 track() calls in ONE
     ht_camshift_track_sequence: every call of every stream within +-1 px / +-0.5 deg of the oracle, >= 95 % exact."""
-    import torch
+    from hipmem import DeviceArray
 
     w, h, n, nv, calls = 320, 240, 256, 4, 60
     vers = _c3_streams(n, w, h, nv)
-    dev = [torch.from_numpy(vers[v]).cuda() for v in range(nv)]
-    c = Context()
+    c = Context()  # first: ht_create selects the device
+    dev = [DeviceArray(vers[v]) for v in range(nv)]
     try:
         c.set_geometry(w, h, n)
-        c.bind_device(dev[0].data_ptr(), n)
+        c.bind_device(dev[0].ptr, n)
         c.camshift_reserve(n)
         c.detect_enqueue(0)
         hits, counts = c.detect_collect(cap=1 << 17)
@@ -106,7 +106,7 @@ def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
         rects = [(math.floor(best["x"][f]), math.floor(best["y"][f]), math.floor(best["width"][f]), math.floor(best["height"][f]))
                  if best["neighbors"][f] > 0 else (w // 4, h // 4, w // 2, h // 2) for f in range(n)]
         c.camshift_init(rects)
-        got = c.camshift_track_sequence([dev[(k + 1) % nv].data_ptr() for k in range(calls)], n, calc_angles=True, fetch="all")
+        got = c.camshift_track_sequence([dev[(k + 1) % nv].ptr for k in range(calls)], n, calc_angles=True, fetch="all")
         assert got.shape == (calls, n)
         stats = []
         for f in range(n):
@@ -120,19 +120,25 @@ def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
         # the sequence call == the same calls issued one by one
         c.camshift_init(rects)
         for k in range(3):
-            c.bind_device(dev[(k + 1) % nv].data_ptr(), n)
+            c.bind_device(dev[(k + 1) % nv].ptr, n)
             one = c.camshift_track(n, calc_angles=True)
             assert one.tobytes() == got[k].tobytes(), k
         px, ncalls = c.camshift_stats(n, reset=True)
         assert np.all(ncalls == 3) and np.all(px > 0)
     finally:
         c.close()
+        for d in dev:
+            d.free()
 
 
-def test_camshift_histograms_bin_for_bin():
+@pytest.mark.parametrize("fused", [False, True], ids=["chunked", "fused"])
+def test_camshift_histograms_bin_for_bin(fused, monkeypatch):
     """camshift.Histogram (camshift.js:49-72): the model histogram of initTracker and the full-frame histogram of track(),
     read back from the device, equal the oracle's in every one of the 4096 bins — incl. a rect reaching outside the frame
-    (transparent black -> bin 0), an odd pixel count, and a frame cut into many chunk histograms."""
+    (transparent black -> bin 0), an odd pixel count, and a frame cut into many chunk histograms; on both schedules (the
+    single-launch kernel keeps its histogram in LDS and only writes it out under HT_DEBUG_CS_KEEP_HIST)."""
+    monkeypatch.setenv("HT_DEBUG_CS_FUSED_MIN", "1" if fused else "1000000")
+    monkeypatch.setenv("HT_DEBUG_CS_KEEP_HIST", "1")
     for (w, h, rect) in [(320, 240, (100, 60, 90, 80)), (321, 243, (-10, -5, 60, 70)), (1280, 720, (1200, 650, 200, 200))]:
         a = synth.blob_frame(w, h, w // 2, h // 2, w // 6, h // 8, (4, 3, 5), (200, 60, 40), seed=5)
         b = synth.blob_frame(w, h, w // 2 + 3, h // 2 + 2, w // 6, h // 8, (4, 3, 5), (200, 60, 40), seed=6)

@@ -259,3 +259,24 @@ class Context:
     @property
     def stream(self) -> int:
         return int(self._lib.ht_stream(self._h) or 0)
+
+
+def device_count() -> int:
+    return int(native.lib().ht_device_count())
+
+
+def allgather_best_faces(ctxs, best_per_rank) -> np.ndarray:
+    """Single-process multi-GPU exchange (ht_allgather_best_faces): ctxs[i] lives on GPU i and produced best_per_rank[i]
+    (ht_best_faces output, equal lengths).  Returns the gathered [nranks, frames_per_rank] table after every rank's copy was
+    checked to be identical."""
+    n = len(ctxs)
+    per = len(best_per_rank[0])
+    arrs = [np.ascontiguousarray(b, dtype=RECT_DTYPE) for b in best_per_rank]
+    assert all(len(a) == per for a in arrs)
+    cp = (C.c_void_p * n)(*[c._h.value for c in ctxs])
+    bp = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    out = np.zeros((n, per), dtype=RECT_DTYPE)
+    st = native.lib().ht_allgather_best_faces(cp, n, bp, per, out.ctypes.data)
+    if st != 0:
+        raise HtError(st, native.lib().ht_last_error(ctxs[0]._h).decode())
+    return out

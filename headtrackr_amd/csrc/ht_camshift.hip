@@ -18,7 +18,9 @@
 // reference's column-major scalar loop, so results are equal up to rounding in the last bits of xc/yc — the
 // acceptance bound of BASELINE.json (+-1 px, +-0.5 deg) covers the rare truncation flips this can cause.
 #include <cmath>
+#include <cstring>
 #include <map>
+#include <string>
 #include <vector>
 
 #include <dlfcn.h>
@@ -768,7 +770,7 @@ Rccl &rccl() {
 
 extern "C" ht_status ht_allgather_records(ht_ctx *const *ctxs, int32_t nranks, void *const *records_dev, size_t bytes_per_rank) {
     if (!ctxs || !records_dev || nranks <= 0 || bytes_per_rank == 0) return HT_ERR_INVALID;
-    if (nranks == 1) return HT_OK;
+    if (nranks == 1 && !getenv("HT_DEBUG_FORCE_RCCL")) return HT_OK;  // (the knob runs RCCL with one rank: dlopen + ncclCommInitAll + ncclAllGather on a 1-GPU box)
     std::vector<int> devs(nranks);
     for (int i = 0; i < nranks; i++) {
         if (!ctxs[i] || !records_dev[i]) return HT_ERR_INVALID;
@@ -795,6 +797,52 @@ extern "C" ht_status ht_allgather_records(ht_ctx *const *ctxs, int32_t nranks, v
     for (int i = 0; i < nranks; i++) {
         HT_HIP(ctxs[i], hipSetDevice(ctxs[i]->device));
         HT_HIP(ctxs[i], hipStreamSynchronize(ctxs[i]->stream));
+    }
+    return HT_OK;
+}
+
+extern "C" int32_t ht_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// Single-process multi-GPU exchange of the per-frame bounding boxes: rank i's ht_best_faces output goes into slot i of a
+// device buffer on ITS GPU, one ncclAllGather per rank over xGMI, then every rank's gathered table is read back and compared —
+// all ranks must hold the same table — and the table is returned.
+extern "C" ht_status ht_allgather_best_faces(ht_ctx *const *ctxs, int32_t nranks, const ht_rect *const *best, int32_t frames_per_rank, ht_rect *gathered) {
+    if (!ctxs || !best || !gathered || nranks <= 0 || frames_per_rank <= 0) return HT_ERR_INVALID;
+    const size_t per = sizeof(ht_rect) * (size_t)frames_per_rank, total = per * (size_t)nranks;
+    std::vector<void *> bufs(nranks, nullptr);
+    for (int i = 0; i < nranks; i++) {
+        ht_ctx *c = ctxs[i];
+        if (!c || !best[i]) return HT_ERR_INVALID;
+        HT_HIP(c, hipSetDevice(c->device));
+        if (c->d_gather_bytes < total) {
+            HT_HIP(c, hipStreamSynchronize(c->stream));
+            if (c->d_gather) (void)hipFree(c->d_gather);
+            c->d_gather = nullptr;
+            c->d_gather_bytes = 0;
+            if (hipMalloc(&c->d_gather, total) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "ht_allgather_best_faces: hipMalloc failed");
+            c->d_gather_bytes = total;
+        }
+        HT_HIP(c, hipMemsetAsync(c->d_gather, 0, total, c->stream));
+        HT_HIP(c, hipMemcpyAsync(static_cast<char *>(c->d_gather) + (size_t)i * per, best[i], per, hipMemcpyHostToDevice, c->stream));
+        HT_HIP(c, hipStreamSynchronize(c->stream));  // best[i] is the caller's pageable memory
+        bufs[i] = c->d_gather;
+    }
+    ht_status st = ht_allgather_records(ctxs, nranks, bufs.data(), per);
+    if (st != HT_OK) return st;
+    std::vector<char> other(total);
+    for (int i = 0; i < nranks; i++) {
+        ht_ctx *c = ctxs[i];
+        HT_HIP(c, hipSetDevice(c->device));
+        HT_HIP(c, hipMemcpy(i == 0 ? reinterpret_cast<char *>(gathered) : other.data(), c->d_gather, total, hipMemcpyDeviceToHost));
+        if (i > 0 && std::memcmp(other.data(), gathered, total) != 0)
+            return ht_fail(ctxs[0], HT_ERR_HIP, "ht_allgather_best_faces: rank " + std::to_string(i) + " holds a different table than rank 0 after the all-gather");
     }
     return HT_OK;
 }

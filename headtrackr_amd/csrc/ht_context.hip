@@ -301,6 +301,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
     if (c->d_cs_seq_out) (void)hipFree(c->d_cs_seq_out);
+    if (c->d_gather) (void)hipFree(c->d_gather);
     for (auto &t : c->timers)
         for (auto &p : t.pending) (void)hipEventDestroy(p.first), (void)hipEventDestroy(p.second);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

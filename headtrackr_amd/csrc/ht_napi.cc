@@ -13,6 +13,9 @@
 //   camshiftInit(ctx, rgba, n, w, h, first, Int32Array rects[4n])
 //   camshiftTrack(ctx, rgba, n, w, h, first, calcAngles) -> Float64Array(9n): x,y,width,height,angle,swx,swy,sww,swh
 //   info(ctx) -> {levels, windowsPerFrame, pyramidBytesPerFrame}
+//   deviceCount() -> number of visible GPUs
+//   allgatherBest([ctx0, ctx1, ...], [Float64Array(6*f) per rank: x,y,width,height,confidence,neighbors], framesPerRank)
+//        -> Float64Array(6 * nranks * framesPerRank): every rank's best-face rects after the RCCL all-gather (ht_allgather_best_faces)
 #include <node_api.h>
 
 #include <cstdint>
@@ -496,6 +499,74 @@ napi_value Info(napi_env env, napi_callback_info info) {
     return obj;
 }
 
+napi_value DeviceCount(napi_env env, napi_callback_info) {
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, ht_device_count(), &v));
+    return v;
+}
+
+napi_value AllgatherBest(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    uint32_t nctx = 0, nbest = 0;
+    int32_t per = 0;
+    if (argc < 3 || napi_get_array_length(env, argv[0], &nctx) != napi_ok || napi_get_array_length(env, argv[1], &nbest) != napi_ok || nctx == 0 ||
+        nctx != nbest || !get_i32(env, argv[2], &per) || per <= 0) {
+        napi_throw_type_error(env, nullptr, "allgatherBest([ctx...], [Float64Array...], framesPerRank)");
+        return nullptr;
+    }
+    std::vector<Locked> locks(nctx);  // every rank's context stays locked for the exchange (slots are distinct: no lock-order issue
+                                      // as long as callers pass the contexts in the same order, which headtrackr.js does)
+    std::vector<ht_ctx *> ctxs(nctx);
+    std::vector<std::vector<ht_rect>> rects(nctx, std::vector<ht_rect>((size_t)per));
+    std::vector<const ht_rect *> ptrs(nctx);
+    for (uint32_t i = 0; i < nctx; i++) {
+        napi_value cv, bv;
+        NAPI_OK(napi_get_element(env, argv[0], i, &cv));
+        NAPI_OK(napi_get_element(env, argv[1], i, &bv));
+        Slot *slot = nullptr;
+        if (!get_slot(env, cv, &slot)) return nullptr;
+        for (uint32_t k = 0; k < i; k++)
+            if (locks[k].lk.mutex() == &slot->mu) {
+                napi_throw_error(env, nullptr, "allgatherBest: the same context was passed twice (one context per GPU)");
+                return nullptr;
+            }
+        if (!lock_ctx(env, cv, &locks[i])) return nullptr;
+        ctxs[i] = locks[i].ctx;
+        napi_typedarray_type t;
+        size_t n;
+        void *p;
+        napi_value ab;
+        size_t off;
+        if (napi_get_typedarray_info(env, bv, &t, &n, &p, &ab, &off) != napi_ok || t != napi_float64_array || n < (size_t)per * 6) {
+            napi_throw_type_error(env, nullptr, "allgatherBest: every rank needs a Float64Array of 6 * framesPerRank numbers");
+            return nullptr;
+        }
+        const double *d = static_cast<const double *>(p);
+        for (int f = 0; f < per; f++) {
+            ht_rect &r = rects[i][(size_t)f];
+            r.x = d[6 * f], r.y = d[6 * f + 1], r.width = d[6 * f + 2], r.height = d[6 * f + 3], r.confidence = d[6 * f + 4];
+            r.neighbors = (int32_t)d[6 * f + 5];
+            r.reserved = 0;
+        }
+        ptrs[i] = rects[i].data();
+    }
+    std::vector<ht_rect> out((size_t)nctx * per);
+    ht_status st = ht_allgather_best_faces(ctxs.data(), (int32_t)nctx, ptrs.data(), per, out.data());
+    if (st != HT_OK) return throw_ht(env, ctxs[0], st, "ht_allgather_best_faces");
+    napi_value ab, ta;
+    void *p = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, out.size() * 6 * 8, &p, &ab));
+    double *d = static_cast<double *>(p);
+    for (size_t k = 0; k < out.size(); k++) {
+        d[6 * k] = out[k].x, d[6 * k + 1] = out[k].y, d[6 * k + 2] = out[k].width, d[6 * k + 3] = out[k].height, d[6 * k + 4] = out[k].confidence;
+        d[6 * k + 5] = out[k].neighbors;
+    }
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, out.size() * 6, ab, 0, &ta));
+    return ta;
+}
+
 napi_value Init(napi_env env, napi_value exports) {
     struct {
         const char *name;
@@ -503,7 +574,8 @@ napi_value Init(napi_env env, napi_value exports) {
     } fns[] = {{"createContext", CreateContext}, {"destroy", Destroy},         {"setGeometry", SetGeometry},
                {"detect", Detect},               {"detectAsync", DetectAsync}, {"grayscale", Grayscale},
                {"whitebalance", Whitebalance},   {"camshiftReserve", CamshiftReserve},
-               {"camshiftInit", CamshiftInit},   {"camshiftTrack", CamshiftTrack}, {"info", Info}};
+               {"camshiftInit", CamshiftInit},   {"camshiftTrack", CamshiftTrack}, {"info", Info},
+               {"deviceCount", DeviceCount},     {"allgatherBest", AllgatherBest}};
     for (auto &f : fns) {
         napi_value fn;
         if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn) != napi_ok) return nullptr;

@@ -4,13 +4,35 @@
  * Provides exactly what the per-frame path needs from a 2-D context: getImageData, putImageData, createImageData and
  * drawImage (same-size copies, and scaled copies with this project's declared resampler: centre-aligned bilinear in
  * binary64, round-half-even store — see DESIGN.md "pyramid resampler").  Frames are plain Uint8ClampedArray RGBA.
+ * For the debug overlay of headtrackr.Tracker (main.js:199-219) it also strokes rectangles under translate / rotate:
+ * 1-pixel aliased edges as declared in oracle/canvas_shim.js (a browser canvas would anti-alias; the reference does not care).
  */
 function ImageDataLike(w, h) {
   this.width = w; this.height = h;
   this.data = new Uint8ClampedArray(Math.max(w, 0) * Math.max(h, 0) * 4);
 }
 
-function Ctx(canvas) { this.canvas = canvas; }
+function Ctx(canvas) { this.canvas = canvas; this.strokeStyle = '#000000'; this.xf = [1, 0, 0, 1, 0, 0]; }
+Ctx.prototype.translate = function (tx, ty) { const m = this.xf; m[4] += m[0] * tx + m[2] * ty; m[5] += m[1] * tx + m[3] * ty; };
+Ctx.prototype.rotate = function (angle) {
+  const m = this.xf, co = Math.cos(angle), si = Math.sin(angle);
+  this.xf = [m[0] * co + m[2] * si, m[1] * co + m[3] * si, m[2] * co - m[0] * si, m[3] * co - m[1] * si, m[4], m[5]];
+};
+Ctx.prototype.strokeRect = function (x, y, w, h) {
+  const cv = this.canvas, m = this.xf, rgb = parseInt(String(this.strokeStyle).slice(1), 16);
+  const map = function (px, py) { return [m[0] * px + m[2] * py + m[4], m[1] * px + m[3] * py + m[5]]; };
+  const corners = [map(x, y), map(x + w, y), map(x + w, y + h), map(x, y + h)];
+  for (let e = 0; e < 4; e++) {
+    const from = corners[e], to = corners[(e + 1) % 4], dx = to[0] - from[0], dy = to[1] - from[1];
+    const steps = Math.max(Math.ceil(Math.abs(dx)), Math.ceil(Math.abs(dy)), 1);
+    for (let i = 0; i <= steps; i++) {
+      const px = Math.round(from[0] + dx * i / steps), py = Math.round(from[1] + dy * i / steps);
+      if (px < 0 || py < 0 || px >= cv.width || py >= cv.height) continue;
+      const o = (py * cv.width + px) * 4;
+      cv.pixels[o] = (rgb >> 16) & 255; cv.pixels[o + 1] = (rgb >> 8) & 255; cv.pixels[o + 2] = rgb & 255; cv.pixels[o + 3] = 255;
+    }
+  }
+};
 Ctx.prototype.createImageData = function (w, h) { return new ImageDataLike(w | 0, h | 0); };
 Ctx.prototype.getImageData = function (x, y, w, h) {
   x |= 0; y |= 0; w |= 0; h |= 0;

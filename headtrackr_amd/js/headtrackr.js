@@ -52,20 +52,22 @@ Object.defineProperty(headtrackr, 'cascade', { /* cascade.js:19: the trained fac
   }
 });
 
-/* one native context per (cascade object, interval); contexts own device memory, so they are cached */
+/* one native context per (cascade object, interval, GPU); contexts own device memory, so they are cached */
 const contexts = new WeakMap();
-function contextFor(cascade, interval) {
+function contextFor(cascade, interval, device) {
+  if (device === undefined) device = headtrackr.device | 0;
   let perCascade = contexts.get(cascade);
   if (!perCascade) { perCascade = new Map(); contexts.set(cascade, perCascade); }
-  let c = perCascade.get(interval);
+  const key = interval + '@' + device;
+  let c = perCascade.get(key);
   if (!c) {
-    c = { handle: addon().createContext({ cascade: pack.packCascade(cascade), interval: interval, device: headtrackr.device | 0 }),
-      w: 0, h: 0, batch: 0 };
-    perCascade.set(interval, c);
+    c = { handle: addon().createContext({ cascade: pack.packCascade(cascade), interval: interval, device: device }), w: 0, h: 0, batch: 0, device: device };
+    perCascade.set(key, c);
   }
   return c;
 }
-headtrackr.device = 0; /* HIP device ordinal used for new contexts */
+headtrackr.device = 0; /* HIP device ordinal used by the single-frame (drop-in) entry points */
+headtrackr.deviceCount = function () { return addon().deviceCount(); }; /* GPUs the `devices` option of the batch entry points can name */
 
 /* pyramid level sizes exactly as ccv.js:110-127 computes them (Math.pow / Math.floor in V8), handed to the native
  * side so that no libm difference can move a level boundary */
@@ -223,21 +225,75 @@ headtrackr.ccv.detect_objects_rgba = function (rgba, w, h, cascade, interval, mi
   return groupSeq(hitsToSeq(hits, 0, hits.sum.length, cascade, interval), min_neighbors);
 };
 
-/* n RGBA frames (one Uint8Array of n*w*h*4 bytes) -> Promise of n result lists; runs on the libuv pool */
-headtrackr.ccv.detect_objects_batch = function (frames, n, w, h, cascade, interval, min_neighbors) {
+/* contiguous block of frames owned by `rank` (sizes differ by at most one) — the sharding of BASELINE.json configs[3] */
+function shardRange(total, rank, world) {
+  const base = Math.floor(total / world), rem = total % world;
+  const start = rank * base + Math.min(rank, rem);
+  return [start, start + base + (rank < rem ? 1 : 0)];
+}
+
+/* facetrackr's choice among the grouped rects of one frame (facetrackr.js:157-165: strict '>', first maximum wins) */
+function bestOf(rects) {
+  let best;
+  for (let i = 0; i < rects.length; i++) if (best === undefined || rects[i].confidence > best.confidence) best = rects[i];
+  return best;
+}
+
+/* n RGBA frames (one Uint8Array of n*w*h*4 bytes) -> Promise of n result lists; runs on the libuv pool.
+ * opts.devices = [0, 1, ...]: the frames are block-sharded over these GPUs (one native context and one pool job per GPU, all in
+ * flight together); opts.gather: after the detection every GPU's best-face rect per frame (facetrackr.js:147-175) is
+ * all-gathered over RCCL / xGMI so that every GPU holds the whole batch's bounding boxes; the gathered table comes back as
+ * result.best = [{x, y, width, height, confidence, neighbors} | null per frame]. */
+headtrackr.ccv.detect_objects_batch = function (frames, n, w, h, cascade, interval, min_neighbors, opts) {
   cascade = cascade || headtrackr.cascade;
   interval = interval === undefined ? 5 : interval;
   min_neighbors = min_neighbors === undefined ? 1 : min_neighbors;
-  const c = contextFor(cascade, interval);
-  ensureGeometry(c, w, h, n, cascade, interval);
-  return addon().detectAsync(c.handle, frames, n, w, h, addon().INPUT_RGBA).then(function (hits) {
-    const out = [];
-    let k = 0;
-    for (let f = 0; f < n; f++) {
-      out.push(groupSeq(hitsToSeq(hits, k, k + hits.counts[f], cascade, interval), min_neighbors));
-      k += hits.counts[f];
+  opts = opts || {};
+  const devices = (opts.devices && opts.devices.length) ? opts.devices : [headtrackr.device | 0];
+  const world = Math.min(devices.length, n);
+  const fbytes = w * h * 4;
+  const jobs = [];
+  for (let r = 0; r < world; r++) {
+    const span = shardRange(n, r, world), cnt = span[1] - span[0];
+    const c = contextFor(cascade, interval, devices[r]);
+    ensureGeometry(c, w, h, cnt, cascade, interval);
+    const view = frames.subarray(span[0] * fbytes, span[1] * fbytes);
+    jobs.push(addon().detectAsync(c.handle, view, cnt, w, h, addon().INPUT_RGBA).then(function (hits) {
+      const out = [];
+      let k = 0;
+      for (let f = 0; f < cnt; f++) {
+        out.push(groupSeq(hitsToSeq(hits, k, k + hits.counts[f], cascade, interval), min_neighbors));
+        k += hits.counts[f];
+      }
+      return { ctx: c, rects: out };
+    }));
+  }
+  return Promise.all(jobs).then(function (parts) {
+    let all = [];
+    parts.forEach(function (p) { all = all.concat(p.rects); });
+    if (opts.gather) {
+      const per = Math.ceil(n / world);
+      const recs = parts.map(function (p) {
+        const a = new Float64Array(6 * per); /* padding rows stay zero */
+        p.rects.forEach(function (rects, f) {
+          const b = bestOf(rects);
+          if (b) a.set([b.x, b.y, b.width, b.height, b.confidence, b.neighbors === undefined ? 1 : b.neighbors], 6 * f);
+          else a[6 * f + 4] = -10000; /* facetrackr.js:239 */
+        });
+        return a;
+      });
+      const g = addon().allgatherBest(parts.map(function (p) { return p.ctx.handle; }), recs, per);
+      const best = [];
+      for (let r = 0; r < world; r++) {
+        const span = shardRange(n, r, world);
+        for (let f = 0; f < span[1] - span[0]; f++) {
+          const o = 6 * (r * per + f);
+          best.push(g[o + 5] > 0 ? { x: g[o], y: g[o + 1], width: g[o + 2], height: g[o + 3], confidence: g[o + 4], neighbors: g[o + 5] } : null);
+        }
+      }
+      all.best = best;
     }
-    return out;
+    return all;
   });
 };
 

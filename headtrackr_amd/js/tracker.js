@@ -139,6 +139,9 @@ module.exports = function install(headtrackr) {
       headPosition: true, whitebalancing: true }, params || {});
     let video = null, canvas = null, ctx = null, smoother = null, facetracker, headposition, timer = null;
     let fov = 0, run = false, faceFound = false, firstRun = true, detectionStart;
+    /* debug overlay (main.js:42-50): a canvas that receives the back-projection (facetrackr.js:194-196) and the face boxes */
+    if (params.debug === undefined || !params.debug || params.debug.tagName !== 'CANVAS') params.debug = false;
+    const debugContext = params.debug ? params.debug.getContext('2d') : null;
     const diagonals = [];
     const self = this;
     this.status = '';
@@ -158,7 +161,7 @@ module.exports = function install(headtrackr) {
     this.step = function () {
       if (video && video !== canvas) ctx.drawImage(video, 0, 0, canvas.width, canvas.height);
       if (facetracker === undefined) {
-        facetracker = new headtrackr.facetrackr.Tracker({ calcAngles: params.calcAngles, whitebalancing: params.whitebalancing, onEvent: params.onEvent });
+        facetracker = new headtrackr.facetrackr.Tracker({ debug: params.debug, calcAngles: params.calcAngles, whitebalancing: params.whitebalancing, onEvent: params.onEvent });
         facetracker.init(canvas);
       }
       facetracker.track();
@@ -170,15 +173,27 @@ module.exports = function install(headtrackr) {
         if (face.detection === 'VJ') {
           if (detectionStart === undefined) detectionStart = (new Date()).getTime();
           if (((new Date()).getTime() - detectionStart) > 5000) status('hints');
+          if (debugContext) { /* detected face on the debug canvas, main.js:199-203 */
+            debugContext.strokeStyle = '#0000CC';
+            debugContext.strokeRect(face.x, face.y, face.width, face.height);
+          }
         }
         if (face.detection === 'CS') {
           detectionStart = undefined;
+          if (debugContext) { /* tracked face, rotated about its centre, main.js:211-219 */
+            debugContext.translate(face.x, face.y);
+            debugContext.rotate(face.angle - (Math.PI / 2));
+            debugContext.strokeStyle = '#00CC00';
+            debugContext.strokeRect((-(face.width / 2)) >> 0, (-(face.height / 2)) >> 0, face.width, face.height);
+            debugContext.rotate((Math.PI / 2) - face.angle);
+            debugContext.translate(-face.x, -face.y);
+          }
           this.status = 'tracking';
           if (face.width === 0 || face.height === 0) { /* lost: zero mass in camshift, main.js:230-248 */
             if (params.retryDetection) {
               status('redetecting');
               facetracker.release(); /* the lost tracker's camshift slot goes back to the pool */
-              facetracker = new headtrackr.facetrackr.Tracker({ whitebalancing: false, calcAngles: params.calcAngles, onEvent: params.onEvent });
+              facetracker = new headtrackr.facetrackr.Tracker({ whitebalancing: false, debug: params.debug, calcAngles: params.calcAngles, onEvent: params.onEvent });
               facetracker.init(canvas);
               faceFound = false;
               headposition = undefined;

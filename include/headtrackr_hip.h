@@ -205,6 +205,15 @@ ht_status ht_camshift_debug_hist(ht_ctx *ctx, int32_t stream, uint32_t *model, u
  * on distinct devices; records_dev[i] points to nranks*bytes_per_rank bytes of device memory on ctxs[i]'s device
  * with rank i's own records already at offset i*bytes_per_rank.  Performs one ncclAllGather per rank in a group. */
 ht_status ht_allgather_records(ht_ctx *const *ctxs, int32_t nranks, void *const *records_dev, size_t bytes_per_rank);
+/* The exchange step of the frame-sharded path for a single-process host (BASELINE.json: "RCCL all-gather of bounding boxes"):
+ * best[i] = rank i's ht_best_faces output for its frames_per_rank frames (host memory; pad short ranks with zero rects).
+ * Uploads every rank's rects into its own GPU's slot, runs ht_allgather_records, reads every rank's table back, requires
+ * them to be identical and returns the table (nranks*frames_per_rank rects, rank-major) — what facetrackr.Tracker.doVJDetection
+ * (facetrackr.js:147-175) would have produced for every frame of the batch, now known on every GPU. */
+ht_status ht_allgather_best_faces(ht_ctx *const *ctxs, int32_t nranks, const ht_rect *const *best, int32_t frames_per_rank,
+                                  ht_rect *gathered);
+/* Number of HIP devices visible to the process (0 if none); the `devices` option of the JS batch entry points indexes them. */
+int32_t ht_device_count(void);
 
 /* ---- measurement --------------------------------------------------------------------------------------- */
 

@@ -22,6 +22,12 @@
  *   i.e. centre-aligned bilinear, edge-clamped to the source rect; exact 2:1 halving = 2x2 box mean;
  *   1:1 is an exact copy.  Sources are treated as opaque (channels resampled independently and
  *   written, not alpha-composited).  A call with any of sw,sh,dw,dh <= 0 draws nothing.
+ * Stroking (debug canvas only, /root/reference/src/main.js:199-219): strokeStyle '#RRGGBB', strokeRect, translate, rotate.  The
+ * reference leaves the rasterisation to the browser (anti-aliased, implementation-defined); declared here as: the four corners
+ * are mapped through the current transform (translate / rotate compose like the canvas spec's), every edge is drawn as a
+ * 1-pixel line without anti-aliasing — n = max(ceil(|dx|), ceil(|dy|), 1) steps, pixel (round(x), round(y)) with Math.round,
+ * colour = strokeStyle, alpha 255, clipped to the canvas.  Every stroke call is also appended to canvas._calls as
+ * [op, args...], which is what the golden vectors pin (the pixels are pinned only relative to this declaration).
  * Other semantics: resizing a canvas clears it to transparent black; getImageData outside the canvas
  * reads transparent black (used by camshift.initTracker, /root/reference/src/camshift.js:206).
  */
@@ -39,7 +45,37 @@ function ImageData(w, h, data) {
 
 function Context2D(canvas) {
   this.canvas = canvas;
+  this.strokeStyle = '#000000';
+  this._m = [1, 0, 0, 1, 0, 0]; /* a b c d e f: x' = a x + c y + e, y' = b x + d y + f */
 }
+
+Context2D.prototype.translate = function (tx, ty) {
+  const m = this._m;
+  m[4] += m[0] * tx + m[2] * ty; m[5] += m[1] * tx + m[3] * ty;
+  this.canvas._calls.push(['translate', tx, ty]);
+};
+Context2D.prototype.rotate = function (ang) {
+  const m = this._m, c = Math.cos(ang), s = Math.sin(ang);
+  const a = m[0] * c + m[2] * s, b = m[1] * c + m[3] * s, cc = m[2] * c - m[0] * s, d = m[3] * c - m[1] * s;
+  m[0] = a; m[1] = b; m[2] = cc; m[3] = d;
+  this.canvas._calls.push(['rotate', ang]);
+};
+Context2D.prototype.strokeRect = function (x, y, w, h) {
+  const cv = this.canvas, m = this._m, col = parseInt(String(this.strokeStyle).slice(1), 16);
+  cv._calls.push(['strokeRect', this.strokeStyle, x, y, w, h]);
+  const P = [[x, y], [x + w, y], [x + w, y + h], [x, y + h]].map(function (p) { return [m[0] * p[0] + m[2] * p[1] + m[4], m[1] * p[0] + m[3] * p[1] + m[5]]; });
+  for (let e = 0; e < 4; e++) {
+    const p = P[e], q = P[(e + 1) & 3], dx = q[0] - p[0], dy = q[1] - p[1];
+    const n = Math.max(Math.ceil(Math.abs(dx)), Math.ceil(Math.abs(dy)), 1);
+    for (let i = 0; i <= n; i++) {
+      const px = Math.round(p[0] + dx * i / n), py = Math.round(p[1] + dy * i / n);
+      if (px >= 0 && py >= 0 && px < cv._w && py < cv._h) {
+        const o = (py * cv._w + px) * 4;
+        cv._buf[o] = (col >> 16) & 255; cv._buf[o + 1] = (col >> 8) & 255; cv._buf[o + 2] = col & 255; cv._buf[o + 3] = 255;
+      }
+    }
+  }
+};
 
 Context2D.prototype.createImageData = function (w, h) {
   return new ImageData(w | 0, h | 0);
@@ -149,6 +185,7 @@ function Canvas(w, h) {
   this._h = (h | 0) > 0 ? (h | 0) : 0;
   this._buf = new Uint8ClampedArray(this._w * this._h * 4);
   this._ctx = null;
+  this._calls = []; /* stroke-call log (see the header) */
 }
 Object.defineProperty(Canvas.prototype, 'width', {
   get: function () { return this._w; },

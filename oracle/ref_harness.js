@@ -235,6 +235,46 @@ function runPipeline(cs, base) {
   return out;
 }
 
+/* The reference's own headtrackr.Tracker (main.js:35-379), unmodified, driven frame by frame: init(video, canvas, false) skips
+ * getUserMedia, the "video" is a shim canvas that already plays (currentTime > 0), and window.setTimeout is replaced by a hook
+ * that parks the loop's callback (main.js:302-304) so that the harness can swap the video frame and fire it.  Records per frame:
+ * status events, the tracking object, the head position event, and — with a debug canvas — the stroke calls the reference made
+ * on it (main.js:199-219) plus the CRC of its pixels under the declared rasterisation. */
+function runMainJs(cs, base) {
+  const out = { name: cs.name, kind: 'mainjs', w: cs.w, h: cs.h, params: cs.params || {}, calls: [] };
+  const video = new shim.Canvas(cs.w, cs.h), canvas = new shim.Canvas(cs.w, cs.h), debug = new shim.Canvas(cs.w, cs.h);
+  video.currentTime = 1; video.paused = false; video.ended = false; video.addEventListener = function () {}; video.style = {};
+  let parked = null;
+  const realSetTimeout = global.setTimeout, realClear = global.clearTimeout;
+  global.setTimeout = function (fn) { parked = fn; return 1; };
+  global.clearTimeout = function () { parked = null; };
+  const status = [], head = [], faceEv = [];
+  const sl = function (e) { status.push(e.status); }, hl = function (e) { head.push([e.x, e.y, e.z]); }, fl = function (e) { faceEv.push(e.detection); };
+  document.addEventListener('headtrackrStatus', sl);
+  document.addEventListener('headtrackingEvent', hl);
+  document.addEventListener('facetrackingEvent', fl);
+  try {
+    const params = Object.assign({ ui: false, debug: cs.debug ? debug : false }, cs.params || {});
+    const tr = new headtrackr.Tracker(params);
+    tr.init(video, canvas, false);
+    for (let i = 0; i < cs.frames.length; i++) {
+      status.length = 0; head.length = 0; debug._calls.length = 0;
+      video.loadRGBA(fs.readFileSync(path.resolve(base, cs.frames[i])));
+      if (i === 0) tr.start(); else { const fn = parked; parked = null; if (fn) fn(); }
+      out.calls.push({ frame: i, status: status.slice(), trackerStatus: tr.status, head: head.length ? head[head.length - 1] : null,
+        strokes: debug._calls.map(function (c) { return c.slice(); }), debug_crc: cs.debug ? crc32All(debug._buf) : null });
+    }
+    out.fov = tr.getFOV();
+    tr.stop();
+  } finally {
+    global.setTimeout = realSetTimeout; global.clearTimeout = realClear;
+    document.removeEventListener('headtrackrStatus', sl);
+    document.removeEventListener('headtrackingEvent', hl);
+    document.removeEventListener('facetrackingEvent', fl);
+  }
+  return out;
+}
+
 function main() {
   const jobFile = process.argv[2], outFile = process.argv[3];
   const job = JSON.parse(fs.readFileSync(jobFile, 'utf8'));
@@ -250,6 +290,7 @@ function main() {
     else if (cs.kind === 'smoother') r = runSmoother(cs);
     else if (cs.kind === 'headposition') r = runHeadposition(cs);
     else if (cs.kind === 'pipeline') r = runPipeline(cs, base);
+    else if (cs.kind === 'mainjs') r = runMainJs(cs, base);
     else throw new Error('unknown case kind ' + cs.kind);
     r.gen = cs.gen;                         /* how make_golden.py synthesised the input (echoed for the tests) */
     res.cases.push(r);

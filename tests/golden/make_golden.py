@@ -109,6 +109,16 @@ def post_cases():
     return cs
 
 
+def mainjs_cases():
+    """The reference's own headtrackr.Tracker loop (main.js) with a debug canvas: whitebalance phase, VJ box, rotated CS boxes,
+    a lost track and the re-detection."""
+    W, H = 320, 240
+    gens = [dict(family="face", faces=[[100, 60, 96]])] * 16 + [dict(family="face", faces=[[100 + 2 * k, 60 + k, 96]]) for k in range(1, 9)] + \
+           [dict(family="face", faces=[], gray=250)] * 2 + [dict(family="face", faces=[[60, 50, 110]])] * 4
+    return [dict(name="mainjs_debug_angles", kind="mainjs", w=W, h=H, debug=True, params=dict(calcAngles=True), gens=gens),
+            dict(name="mainjs_debug_noangles", kind="mainjs", w=W, h=H, debug=True, params=dict(calcAngles=False, smoothing=False), gens=gens[:22])]
+
+
 def run(cases, out_name):
     with tempfile.TemporaryDirectory() as td:
         cache = {}
@@ -150,3 +160,4 @@ if __name__ == "__main__":
     run(camshift_cases(), "camshift.json")
     run(facetrackr_cases(), "facetrackr.json")
     run(post_cases(), "post.json")
+    run(mainjs_cases(), "debug.json")

@@ -59,7 +59,7 @@ check(typeof ht.headposition.Tracker === 'function' && typeof ht.headposition.Tr
 /* the addon must load and expose the C-ABI wrappers even without a GPU */
 try {
   const addon = require(path.join(root, 'headtrackr_amd', 'js', 'headtrackr_hip.node'));
-  ['createContext', 'detect', 'detectAsync', 'grayscale', 'whitebalance', 'camshiftInit', 'camshiftTrack'].forEach(function (k) {
+  ['createContext', 'detect', 'detectAsync', 'grayscale', 'whitebalance', 'camshiftInit', 'camshiftTrack', 'deviceCount', 'allgatherBest'].forEach(function (k) {
     check(typeof addon[k] === 'function', 'addon.' + k);
   });
   out.abi = addon.abiVersion;

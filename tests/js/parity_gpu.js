@@ -111,6 +111,46 @@ job.facetrackr.forEach(function (cs) {
   tr.stop(); /* releases the facade's face tracker (and its camshift slot) */
 });
 
+/* headtrackr.Tracker against the reference's OWN main.js loop (tests/golden/debug.json, recorded by driving the unmodified
+ * headtrackr.Tracker frame by frame): status events per frame, head position, and the debug overlay — the stroke calls made on
+ * the debug canvas (main.js:199-219) and, while every argument so far matched exactly, the canvas pixels (CRC under the declared
+ * 1-pixel rasterisation, back-projection blit of facetrackr.js:194-196 included). */
+(job.mainjs || []).forEach(function (cs) {
+  const g = cs.golden;
+  const statuses = [], heads = [];
+  const video = new Canvas(cs.w, cs.h), canvas = new Canvas(cs.w, cs.h), debug = new Canvas(cs.w, cs.h);
+  const dctx = debug.getContext('2d'), strokes = [];
+  ['translate', 'rotate'].forEach(function (op) { const f = dctx[op]; dctx[op] = function () { strokes.push([op].concat(Array.prototype.slice.call(arguments))); return f.apply(dctx, arguments); }; });
+  const sr = dctx.strokeRect; dctx.strokeRect = function (x, y, w, h) { strokes.push(['strokeRect', dctx.strokeStyle, x, y, w, h]); return sr.call(dctx, x, y, w, h); };
+  const tr = new headtrackr.Tracker(Object.assign({ debug: debug, onEvent: function (t, e) { if (t === 'headtrackrStatus') statuses.push(e.status); if (t === 'headtrackingEvent') heads.push([e.x, e.y, e.z]); } }, g.params));
+  tr.init(video, canvas);
+  let exact = true;
+  g.calls.forEach(function (call, i) {
+    statuses.length = 0; heads.length = 0; strokes.length = 0;
+    video.setFrame(fs.readFileSync(path.resolve(base, cs.frames[i])));
+    tr.step();
+    check(JSON.stringify(statuses) === JSON.stringify(call.status), cs.name + ' frame ' + i + ': status ' + JSON.stringify(statuses) + ' vs ' + JSON.stringify(call.status));
+    if (call.head === null) check(heads.length === 0, cs.name + ' frame ' + i + ': no head event expected');
+    else check(heads.length > 0 && near(heads[heads.length - 1][0], call.head[0], 0.5) && near(heads[heads.length - 1][1], call.head[1], 0.5) && near(heads[heads.length - 1][2], call.head[2], 2.5), cs.name + ' frame ' + i + ': head');
+    check(strokes.length === call.strokes.length, cs.name + ' frame ' + i + ': ' + strokes.length + ' stroke calls vs ' + call.strokes.length);
+    for (let k = 0; k < Math.min(strokes.length, call.strokes.length); k++) {
+      const a = strokes[k], b = call.strokes[k];
+      check(a[0] === b[0] && a.length === b.length, cs.name + ' frame ' + i + ' stroke ' + k + ': ' + a[0] + ' vs ' + b[0]);
+      for (let q = 1; q < Math.min(a.length, b.length); q++) {
+        if (typeof b[q] === 'string') { check(a[q] === b[q], cs.name + ' frame ' + i + ' stroke ' + k + ': style'); continue; }
+        if (b[q] === null) { check(Number.isNaN(a[q]), cs.name + ' frame ' + i + ' stroke ' + k + ': NaN expected'); continue; }
+        const tol = a[0] === 'rotate' ? 0.5 * Math.PI / 180 : (a[0] === 'translate' ? 1 : 4); /* camshift budget: +-1 px, +-0.5 deg, sizes in steps of 4 */
+        check(near(a[q], b[q], tol), cs.name + ' frame ' + i + ' stroke ' + k + ' arg ' + q + ': ' + a[q] + ' vs ' + b[q]);
+        if (a[0] === 'rotate' ? !near(a[q], b[q], 1e-9) : a[q] !== b[q]) exact = false; /* Math.atan2 vs libm atan2: last-bit differences of the angle */
+      }
+    }
+    if (exact) check(crc32(debug.pixels) === call.debug_crc, cs.name + ' frame ' + i + ': debug canvas pixels');
+  });
+  check(exact, cs.name + ': every stroke argument matched the reference exactly');
+  check(near(tr.getFOV(), g.fov, 1.0), cs.name + ': fov');
+  tr.stop();
+});
+
 /* device-slot hygiene (not in the reference): 1000 lost-track / redetect cycles of the facade's tracker replacement must not
  * grow the camshift reservation — every replaced facetrackr.Tracker hands its slot back */
 (function () {
@@ -142,6 +182,29 @@ job.facetrackr.forEach(function (cs) {
       check(res[i].length === gg.length, c.name + ': batch grouped count');
       for (let k = 0; k < Math.min(res[i].length, gg.length); k++) check(res[i][k].x === gg[k].x && res[i][k].confidence === gg[k].confidence, c.name + ': batch grouped[' + k + ']');
     });
+  }
+  /* frame-sharded batch over every visible GPU + RCCL all-gather of the best-face rects (BASELINE.json configs[3] for a JS host):
+   * same rect lists as the single-GPU call, and the gathered table == facetrackr's choice per frame.  On a 1-GPU box this runs
+   * with one rank (no RCCL call; the RCCL path itself is forced in tests/test_gpu_shapes.py). */
+  if (job.detect.length) {
+    const same = job.detect.filter(function (c) { return c.w === 320 && c.h === 240 && c.interval === 5; }).slice(0, 7);
+    const n = same.length, buf = new Uint8Array(n * 320 * 240 * 4);
+    same.forEach(function (c, i) { buf.set(fs.readFileSync(path.resolve(base, c.frame)), i * 320 * 240 * 4); });
+    const ndev = headtrackr.deviceCount();
+    check(ndev >= 1, 'deviceCount() = ' + ndev);
+    const devices = [];
+    for (let d = 0; d < ndev; d++) devices.push(d);
+    const one = await headtrackr.ccv.detect_objects_batch(buf, n, 320, 240, headtrackr.cascade, 5, 1);
+    const res = await headtrackr.ccv.detect_objects_batch(buf, n, 320, 240, headtrackr.cascade, 5, 1, { devices: devices, gather: true });
+    check(res.length === n && res.best && res.best.length === n, 'sharded batch: result shape');
+    for (let i = 0; i < n; i++) {
+      check(JSON.stringify(res[i]) === JSON.stringify(one[i]), 'sharded batch: frame ' + i + ' differs from the single-GPU result');
+      let b;
+      one[i].forEach(function (r) { if (b === undefined || r.confidence > b.confidence) b = r; });
+      if (b === undefined) check(res.best[i] === null, 'gathered best of frame ' + i + ' should be null');
+      else check(res.best[i] !== null && res.best[i].x === b.x && res.best[i].y === b.y && res.best[i].width === b.width && res.best[i].confidence === b.confidence &&
+        res.best[i].neighbors === b.neighbors, 'gathered best of frame ' + i);
+    }
   }
   console.log(JSON.stringify(out));
 })().catch(function (e) { out.ok = false; out.errors.push('exception: ' + e.stack); console.log(JSON.stringify(out)); });

@@ -226,3 +226,38 @@ def test_collect_reports_the_enqueued_batch(cascade):
         assert got.tobytes() == want.tobytes() and np.array_equal(counts, want_counts)
     finally:
         c.close()
+
+
+def test_allgather_best_faces_over_rccl(cascade, monkeypatch):
+    """The single-process exchange step (ht_allgather_best_faces): one context per visible GPU, frames block-sharded, every
+    rank's best-face rects all-gathered over RCCL and checked to be identical on every GPU.  With one GPU the call still goes
+    through dlopen(librccl) + ncclCommInitAll + ncclAllGather (HT_DEBUG_FORCE_RCCL)."""
+    from headtrackr_amd import api, distributed as hd
+
+    monkeypatch.setenv("HT_DEBUG_FORCE_RCCL", "1")
+    ndev = api.device_count()
+    assert ndev >= 1
+    n = 6 * ndev + (1 if ndev > 1 else 0)
+    frames = synth.mixed_batch(n, 320, 240, seed0=1234)
+    per = -(-n // ndev)
+    ctxs, bests = [], []
+    try:
+        for r in range(ndev):
+            a, b = hd.shard_range(n, r, ndev)
+            c = Context(device=r)
+            ctxs.append(c)
+            hits, counts = c.detect_raw(frames[a:b])
+            best = np.zeros(per, dtype=api.RECT_DTYPE)
+            best[: b - a] = c.best_faces(hits, counts, 1)
+            bests.append(best)
+        g = api.allgather_best_faces(ctxs, bests)
+        assert g.shape == (ndev, per)
+        want = ho.best_faces(frames, cascade.blob, 1)
+        for r in range(ndev):
+            a, b = hd.shard_range(n, r, ndev)
+            assert g[r, : b - a].tobytes() == want[a:b].tobytes()
+            assert g[r].tobytes() == bests[r].tobytes()
+        assert int((g["neighbors"] > 0).sum()) >= 2
+    finally:
+        for c in ctxs:
+            c.close()

@@ -46,7 +46,8 @@ def test_js_host_parity_on_gpu(tmp_path):
         return cache[key]
 
     post = load_golden("post.json")
-    job = {"detect": [], "camshift": [], "facetrackr": [], "pipeline": []}
+    dbg = load_golden("debug.json")
+    job = {"detect": [], "camshift": [], "facetrackr": [], "pipeline": [], "mainjs": []}
     for c in det["cases"]:
         if c["w"] > 640:
             continue
@@ -63,8 +64,13 @@ def test_js_host_parity_on_gpu(tmp_path):
             g = {k: c[k] for k in ("params", "calls", "fov")}
             g["whitebalancing"] = False
             job["pipeline"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=[ffile(x, c["w"], c["h"]) for x in c["gen"]], golden=g))
+    for c in dbg["cases"]:
+        job["mainjs"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=[ffile(x, c["w"], c["h"]) for x in c["gen"]],
+                                  golden={k: c[k] for k in ("params", "calls", "fov")}))
     jf = tmp_path / "job.json"
     jf.write_text(json.dumps(job))
+    # (with one visible GPU the sharded call has one rank and skips RCCL; tests/test_gpu_shapes.py::test_allgather_best_faces_over_rccl
+    #  forces the RCCL path — ncclCommInitAll alone takes ~50 s on the test box, once is enough)
     r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "parity_gpu.js"), str(jf)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])

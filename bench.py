@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
-    ap.add_argument("--pipeline", type=int, default=2, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn")
+    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn")
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steady-state work before the warm-up steps (0 for profiler runs)")
     ap.add_argument("--no-sub", action="store_true", help="only the primary workload (no c4 / c3 sub-records)")
     a = ap.parse_args()
@@ -190,7 +190,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     HIP-event roofline of the dominant kernel and the CPU baseline.  Returns the record (rank 0) or None."""
     torch, dist, rank, world, local = env.torch, env.dist, env.rank, env.world, env.local
     from headtrackr_amd import distributed as hd
-    from headtrackr_amd import synth
+    from headtrackr_amd import native, synth
     from headtrackr_amd.api import Context
 
     W, H, nf_default = GEOM[name]
@@ -221,11 +221,13 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     rec_local = torch.zeros((nf_max, hd.RECORD_F64), dtype=torch.float64, device="cuda")
     state = {}
 
+    best_bufs = {id(cx): np.zeros(nf, dtype=native.RECT_DTYPE) for cx in ctxs}
+
     def finish(cx):
-        # raw hits -> seq rects -> ccv's grouping -> facetrackr's best face per frame: all inside the timed step
-        hits, counts = cx.detect_collect(cap=1 << 17)
-        best = cx.best_faces(hits, counts, 1)
-        state["hits"], state["best"] = hits, best
+        # raw hits -> sorted -> seq rects -> ccv's grouping -> facetrackr's best face per frame: all inside the timed step
+        # (one C-ABI call, ht_detect_collect_best: the Python host was the limiter of a 0.3 ms step with three calls and copies)
+        best, nhits = cx.detect_collect_best(1, best_bufs[id(cx)])
+        state["nhits"], state["best"] = nhits, best
         if world > 1:  # the path's one exchange step: every rank ends up with every frame's best-face rectangle
             rec = hd.pack_best_records(best, f0, nf_max)
             rec_local.copy_(torch.from_numpy(rec), non_blocking=False)
@@ -314,7 +316,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     rec["device_ms_per_step"] = round(dev_ms, 5)
     rec["path_hbm_gbs"] = round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2)
     rec["path_hbm_frac"] = round(b_detect * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-    rec["hits_per_step"] = int(len(state["hits"]))
+    rec["hits_per_step"] = int(state["nhits"])
     rec["faces_per_step"] = int((state["best"]["neighbors"] > 0).sum())
     if full:
         ctx.detect_enqueue(a.flags | 16)  # one extra untimed pass with HT_SCAN_STATS for the survival curve

@@ -120,6 +120,14 @@ class Context:
         self._check(self._lib.ht_detect_collect(self._h, buf.ctypes.data, cap, counts.ctypes.data, C.byref(total)))
         return buf[: total.value].copy(), counts[: self.nframes]
 
+    def detect_collect_best(self, min_neighbors: int = 1, out: np.ndarray | None = None):
+        """ht_detect_collect + ht_best_faces in one C call: (best rect per frame of the enqueued batch, raw hit count)."""
+        if out is None or len(out) < self.nframes:
+            out = np.zeros(max(1, self.nframes), dtype=RECT_DTYPE)
+        total = C.c_uint32(0)
+        self._check(self._lib.ht_detect_collect_best(self._h, min_neighbors, out.ctypes.data, C.byref(total)))
+        return out[: self.nframes], total.value
+
     def detect_raw(self, frames: np.ndarray, flags: int = HT_INPUT_RGBA, cap: int = 1 << 16):
         """ccv.grayscale + ccv.detect_objects(..., min_neighbors = 0) for a batch: (hits, per-frame counts)."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)

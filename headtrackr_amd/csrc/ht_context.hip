@@ -980,6 +980,20 @@ extern "C" ht_status ht_best_faces(const ht_ctx *c, const ht_hit *hits, const ui
     return HT_OK;
 }
 
+extern "C" ht_status ht_detect_collect_best(ht_ctx *c, int32_t min_neighbors, ht_rect *best, uint32_t *total_hits) {
+    if (!c || !best) return HT_ERR_INVALID;
+    if (!c->enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_collect_best: nothing enqueued");
+    const int nfr = c->enq_nframes;
+    // the context's own buffers: nothing but the per-frame rects crosses the ABI (a batch server calls this once per batch)
+    if (c->h_collect_hits.size() < (size_t)c->hit_capacity) c->h_collect_hits.resize(c->hit_capacity);
+    c->h_collect_counts.resize((size_t)std::max(nfr, 1));
+    uint32_t total = 0;
+    ht_status st = ht_detect_collect(c, c->h_collect_hits.data(), c->hit_capacity, c->h_collect_counts.data(), &total);
+    if (total_hits) *total_hits = total;
+    if (st != HT_OK) return st;
+    return ht_best_faces(c, c->h_collect_hits.data(), c->h_collect_counts.data(), nfr, min_neighbors, best);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // measurement
 

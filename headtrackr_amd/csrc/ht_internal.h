@@ -231,6 +231,8 @@ struct ht_ctx {
     uint8_t *h_pinned = nullptr;  // pinned staging: [HtCounters][HT_PINNED_HITS x ht_hit], one D2H + one sync per batch
     unsigned long long *d_stats = nullptr;      // [HT_STAT_SHARDS][64], only touched with HT_SCAN_STATS
     unsigned long long h_stage_in[64] = {0};   // windows that entered stage j ([nstages] = full survivors), last collected batch
+    std::vector<ht_hit> h_collect_hits;        // ht_detect_collect_best: sorted raw hits of the last batch
+    std::vector<uint32_t> h_collect_counts;    // ... and their per-frame counts
     bool stats_enqueued = false;
     bool enqueued = false;
 

@@ -177,6 +177,10 @@ ht_status ht_group_rects(const ht_rect *seq, uint32_t n, int32_t min_neighbors, 
 ht_status ht_best_faces(const ht_ctx *ctx, const ht_hit *hits, const uint32_t *counts, int32_t nframes, int32_t min_neighbors,
                         ht_rect *best);
 
+/* ht_detect_collect + ht_best_faces in one call for batch hosts: waits for the enqueued batch, sorts and groups its raw hits and
+ * writes one rect per frame of the batch (facetrackr.js:147-175); the hits stay in the context.  *total_hits = raw hits found. */
+ht_status ht_detect_collect_best(ht_ctx *ctx, int32_t min_neighbors, ht_rect *best, uint32_t *total_hits);
+
 /* ---- camshift: camshift.Tracker (camshift.js:148-354), one tracker per stream ----------------------------- */
 
 /* (Re)allocates per-stream tracker state for n streams. */

@@ -32,6 +32,9 @@ def test_c2_batch_every_frame_vs_oracle(cascade):
         for k in ("x", "y", "width", "height", "confidence", "neighbors"):
             assert np.array_equal(best[k], want[k]), k
         assert int((best["neighbors"] > 0).sum()) > n // 3 * 0.9
+        c.detect_enqueue(0)  # the one-call form the batch bench uses
+        best2, nhits = c.detect_collect_best(1)
+        assert nhits == len(hits) and best2.tobytes() == best.tobytes()
     finally:
         c.close()
 

@@ -199,13 +199,19 @@ __device__ __forceinline__ uint32_t rs_pixel_f64(const uint8_t *p, const uint8_t
 // ties (a quarter of all pixels) would all take the fallback: it is computed in integers instead, RNE included.
 constexpr float RS_EPS = 1.0f / 8192.0f;
 
-__device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int (&ia)[4], const int (&ib)[4], const double (&cu)[4], const double (&ct)[4],
-                                                   const float (&ctf)[4], double ru, double rt, float rtf, int npx, uint32_t mode) {
+// The binary64 taps are only needed by the rare fallback (and the HT_DEBUG_RS_NOFAST build): they are fetched from the tap
+// tables in LDS there (coltap[k] = column tap of pixel k, rowtap = the row's tap) instead of living in 20 VGPRs.
+__device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int (&ia)[4], const int (&ib)[4], const RsTap *const (&coltap)[4],
+                                                   const float (&ctf)[4], const RsTap *rowtap, float rtf, int npx, uint32_t mode) {
     uint32_t o = 0;
+#define cu(k) (coltap[k]->u)
+#define ct(k) (coltap[k]->t)
+#define ru (rowtap->u)
+#define rt (rowtap->t)
     if (mode & 2u) {  // HT_DEBUG_RS_NOFAST: the declared binary64 sequence for every pixel (A/B and cross-check)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (k < npx) o |= rs_pixel_f64(row + ia[k], row + ib[k], cu[k], ct[k], ru, rt) << (8 * k);
+            if (k < npx) o |= rs_pixel_f64(row + ia[k], row + ib[k], cu(k), ct(k), ru, rt) << (8 * k);
         return o;
     }
     if (mode & 1u) {
@@ -239,15 +245,19 @@ __device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int
         for (int k = 0; k < 4; k++) {
             if (need & (1u << k)) {
                 o &= ~(0xffu << (8 * k));
-                o |= rs_pixel_f64(row + ia[k], row + ib[k], cu[k], ct[k], ru, rt) << (8 * k);
+                o |= rs_pixel_f64(row + ia[k], row + ib[k], cu(k), ct(k), ru, rt) << (8 * k);
             }
         }
     }
     return o;
+#undef cu
+#undef ct
+#undef ru
+#undef rt
 }
 
 #ifndef HT_RS_WPS
-#define HT_RS_WPS 1
+#define HT_RS_WPS 6  // waves per SIMD the register allocator leaves room for: 78 VGPRs without spills (measured: 5 -> 6 waves -5 %; 7 / 8 spill and lose)
 #endif
 #ifndef HT_RS_EXPERIMENT
 #define HT_RS_EXPERIMENT 0  // timing experiments only (results are wrong): 1 = no pixel arithmetic, 2 = no source loads
@@ -331,12 +341,12 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         __syncthreads();
         RS_STAMP(1);
         int ia[4], ib[4];
-        double cu[4], ct[4];
+        const RsTap *coltap[4];
         float ctf[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const RsTap tp = s_col[min(x0 - X0 + k, ncols - 1)];
-            ia[k] = tp.a - xa, cu[k] = tp.u, ct[k] = tp.t, ctf[k] = (float)tp.t;
+            coltap[k] = &s_col[min(x0 - X0 + k, ncols - 1)];
+            ia[k] = coltap[k]->a - xa, ctf[k] = (float)coltap[k]->t;
             ib[k] = ia[k] + 1;
             asm volatile("" : "+v"(ib[k]));  // opaque to the optimiser: keeps the left / right taps separate ds_read_u8 (see rs_pixel_f64)
         }
@@ -362,9 +372,9 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
                 const int y = yt + 16 * q;
                 o[q] = 0;
                 if (q < np && y < dh && npx > 0) {
-                    const RsTap ry = s_row[y - Y0];
-                    if (HT_RS_EXPERIMENT == 1) o[q] = *reinterpret_cast<const uint32_t *>(s_src + (ry.a - ya) * RS_SP + (ia[0] & ~3));
-                    else o[q] = rs_pixels4_lds(s_src + (ry.a - ya) * RS_SP, ia, ib, cu, ct, ctf, ry.u, ry.t, (float)ry.t, npx, mode);
+                    const RsTap *ry = &s_row[y - Y0];
+                    if (HT_RS_EXPERIMENT == 1) o[q] = *reinterpret_cast<const uint32_t *>(s_src + (ry->a - ya) * RS_SP + (ia[0] & ~3));
+                    else o[q] = rs_pixels4_lds(s_src + (ry->a - ya) * RS_SP, ia, ib, coltap, ctf, ry, (float)ry->t, npx, mode);
                 }
             }
 #ifdef HT_RS_TIMELINE

@@ -37,8 +37,9 @@ constexpr int TXH = 64;                 // tile width  in half-window steps X'
 #define HT_TILE_TYH 32
 #endif
 #ifndef HT_TILE_WPS
-#define HT_TILE_WPS 5  // waves per SIMD the register allocator must leave room for: 5 workgroups per CU (96 VGPRs, 30.5 KB LDS each);
-                       // measured: 4 -> 5 is -15 % on the tile kernel, 6..8 (with smaller tiles) no further gain
+#define HT_TILE_WPS 6  // waves per SIMD the register allocator must leave room for: 6 workgroups per CU (80 VGPRs, no spills; 26.4 KB of LDS
+                       // each now that the survivor queue lives in the unused tails of the plane-1/2 rows).  Measured: 4 -> 5 workgroups
+                       // -15 %, 5 -> 6 another -7 % (C2) / -6 % (C4) on the tile kernel.
 #endif
 constexpr int TYH = HT_TILE_TYH;        // tile height in half-window steps Y'
 #ifndef HT_TILE_NT
@@ -149,7 +150,19 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     // 4 workgroups per CU.
     constexpr int NQ = HT_TILE_INPLACE ? 1 : 2;
     constexpr int QX = HT_TILE_INPLACE ? 0 : 1;  // cur ^ QX = index of the output queue
+#ifndef HT_TILE_QIN12
+#define HT_TILE_QIN12 1
+#endif
+#if HT_TILE_QIN12 && HT_TILE_INPLACE
+    // The unified-base layout gives the plane-1 / plane-2 rows a pitch of 2 * PITCH0 = 304 bytes of which only the first 160
+    // hold cells: the in-place survivor queue lives in the unused tail of those rows (64 u16 entries per row, 43 rows = 2752 >=
+    // MAXWIN) instead of 4 KB of its own — 26.4 KB of LDS per workgroup = 6 workgroups per CU instead of 5.
+    static_assert(G_PITCH - 160 >= 128 && GH * 64 >= MAXWIN, "queue does not fit the row tails");
+#define QB(qi_, i_) (*reinterpret_cast<uint16_t *>(&lds[P12_BASE + 160 + ((uint32_t)(i_) >> 6) * G_PITCH + (((uint32_t)(i_)&63u) << 1)]))
+#else
     __shared__ uint16_t qbuf[NQ][MAXWIN];
+#define QB(qi_, i_) (qbuf[qi_][i_])
+#endif
     __shared__ uint32_t s_nout;
     __shared__ uint32_t s_qbase;
     __shared__ uint32_t s_F[64];  // sparse phase: per-survivor integer stage sums assembled from the 4 waves' slices
@@ -292,8 +305,8 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 uint32_t b0 = 0;
                 if (lane == 0) b0 = atomicAdd(&s_nout, c0 + c1);
                 b0 = __builtin_amdgcn_readfirstlane(b0);
-                if (pass[0]) qbuf[cur ^ QX][b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = (uint16_t)id[0];
-                if (pass[1]) qbuf[cur ^ QX][b0 + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint16_t)id[1];
+                if (pass[0]) QB(cur ^ QX, b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) = (uint16_t)id[0];
+                if (pass[1]) QB(cur ^ QX, b0 + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) = (uint16_t)id[1];
             }
         }
         if (tid == 0 && my_stats) atomicAdd(&my_stats[0], (unsigned long long)(uint32_t)(tw * th));
@@ -320,7 +333,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             const uint32_t room = qb < queue_cap ? queue_cap - qb : 0u;
             const uint32_t npush = min(n_in, room);
             for (uint32_t i = tid; i < npush; i += NT) {
-                const uint32_t id = qbuf[cur][qoff + i];
+                const uint32_t id = QB(cur, qoff + i);
                 const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
                 const uint32_t ax = (uint32_t)X0 + xx, ay = (uint32_t)Y0 + yy;
                 HtQueueEntry e;
@@ -349,7 +362,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             if (tid < 64u) s_F[tid] = 0u;
             __syncthreads();
             const bool valid = lane < n_in;
-            const uint32_t id = valid ? (uint32_t)qbuf[cur][qoff + lane] : 0u;
+            const uint32_t id = valid ? (uint32_t)QB(cur, qoff + lane) : 0u;
             const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
             const uint32_t B = 2u * (yy * PITCH0 + xx);
             const uint32_t part = ht_gen_stage_slice(s, (int)wv, lds + B);
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                     pass = !(eval_stage_lds(lds, B, F, st.count) < st.threshold);
                 const unsigned long long m = __ballot(pass);
                 const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (pass) qbuf[cur ^ QX][pre] = (uint16_t)id;
+                if (pass) QB(cur ^ QX, pre) = (uint16_t)id;
                 if (lane == 0) s_nout = (uint32_t)__popcll(m);
             }
         } else if (GEN && s == 1 && n_in > (uint32_t)NT) {
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 for (int u = 0; u < 2; u++) {
                     const uint32_t pos = base + u * NT + tid;
                     valid[u] = pos < n_in;
-                    id[u] = valid[u] ? (uint32_t)qbuf[cur][qoff + pos] : 0u;
+                    id[u] = valid[u] ? (uint32_t)QB(cur, qoff + pos) : 0u;
                 }
                 if (HT_TILE_INPLACE) __syncthreads();  // both entries are in registers before survivors overwrite the queue
 #pragma unroll
@@ -397,8 +410,8 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                     uint32_t b0 = 0;
                     if (lane == 0) b0 = atomicAdd(&s_nout, c0 + c1);
                     b0 = __builtin_amdgcn_readfirstlane(b0);
-                    if (pass[0]) qbuf[cur ^ QX][b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))] = (uint16_t)id[0];
-                    if (pass[1]) qbuf[cur ^ QX][b0 + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))] = (uint16_t)id[1];
+                    if (pass[0]) QB(cur ^ QX, b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) = (uint16_t)id[0];
+                    if (pass[1]) QB(cur ^ QX, b0 + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) = (uint16_t)id[1];
                 }
             }
         } else
@@ -406,7 +419,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             const uint32_t pos = base + tid;
             bool valid = pos < n_in;
             uint32_t id = 0;
-            if (valid) id = (s == 0) ? pos : (uint32_t)qbuf[cur][qoff + pos];
+            if (valid) id = (s == 0) ? pos : (uint32_t)QB(cur, qoff + pos);
             if (HT_TILE_INPLACE && s > 0) __syncthreads();  // every entry of this chunk is in a register before survivors overwrite the queue
             // Survivors are compacted, so the waves behind the last survivor have no valid lane: they skip the stage body
             // (wave-uniform branch; the barrier above and the one after the loop are still hit by every wave).  With 65..255
@@ -436,7 +449,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 if (!last) {
                     if (lane == 0) b0 = atomicAdd(&s_nout, cnt);
                     b0 = __builtin_amdgcn_readfirstlane(b0);
-                    if (pass) qbuf[cur ^ QX][b0 + pre] = (uint16_t)id;
+                    if (pass) QB(cur ^ QX, b0 + pre) = (uint16_t)id;
                 } else {
                     if (lane == 0) b0 = atomicAdd(&ctr->nhits, cnt);
                     b0 = __builtin_amdgcn_readfirstlane(b0);

@@ -15,13 +15,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-short = {"k_gray_linear": "gray", "k_resample": "resample", "k_resample_tail": "resample_tail", "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep"}
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+short = {"k_gray_linear": "gray", "k_resample": "resample", "k_resample_tail": "resample_tail", "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep",
+         "k_scan_deep_lds": "scan_deep", "k_cs_track_fused": "cs_track", "k_cs_hist": "cs_hist", "k_cs_meanshift": "cs_meanshift", "k_cs_init": "cs_init"}
 traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/gpu_pmc.sh): bytes = "
            "(2*FETCH_SIZE + WRITE_SIZE)*1024.  On gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section); "
            "calibrated here on k_gray_linear, whose traffic is known exactly (reads W*H*4, writes W*H per frame): see gray_check. "
            "Averages per launch; k_resample is the mean over its launches per step (one per pyramid generation; the last generations are one k_resample_tail launch)."}
-for wl in ("c2", "c4"):
+for wl in ("c2", "c4", "c3"):
     ks = glob.glob(os.path.join(G, f"prof_{wl}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
         shutil.copy(ks[0], os.path.join(P, f"{tag}_{wl}_kernel_stats.csv"))
@@ -54,15 +55,12 @@ for wl in ("c2", "c4"):
             t[short[k]] = round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     if t:
         traffic[wl] = t
-    bj = os.path.join(G, f"bench_{wl}.json")
+for name in ("default", "c5"):
+    bj = os.path.join(G, f"bench_{name}.json")
     if os.path.exists(bj):
-        shutil.copy(bj, os.path.join(P, f"{tag}_bench_{wl}.json"))
-for wl in ("c3", "c5"):
-    bj = os.path.join(G, f"bench_{wl}.json")
-    if os.path.exists(bj):
-        shutil.copy(bj, os.path.join(P, f"{tag}_bench_{wl}.json"))
+        shutil.copy(bj, os.path.join(P, f"{tag}_bench_{name}.json"))
 if len(traffic) > 1:
-    nf = {"c2": (256, 320, 240), "c4": (128, 1280, 720)}
+    nf = {"c2": (256, 320, 240), "c4": (128, 1280, 720), "c3": (256, 320, 240)}
     traffic["gray_check"] = {wl: {"measured": traffic[wl].get("gray"), "known": nf[wl][0] * nf[wl][1] * nf[wl][2] * 5} for wl in traffic if wl in nf}
     json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 print(sorted(os.listdir(P)))

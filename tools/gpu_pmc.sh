@@ -8,7 +8,7 @@ cd /tmp
 i=0
 for set in "${@:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY}"; do
   i=$((i+1))
-  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_${WL}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 3 --warmup 1 --cpu-seconds 0 --prewarm 0 > $OUT/pmc_${WL}_$i.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_${WL}_$i -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps $( [ $WL = c3 ] && echo 1 || echo 3 ) --warmup 1 --cpu-seconds 0 --prewarm 0 --pipeline 1 --no-sub > $OUT/pmc_${WL}_$i.log 2>&1
   echo "set $i: $set -> exit $?"
   python - <<PY
 import csv,glob,collections
@@ -16,7 +16,8 @@ fs=glob.glob("$OUT/pmc_${WL}_$i/**/*counter_collection.csv", recursive=True)
 if not fs: print("no counter csv"); raise SystemExit
 agg=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.Counter()
 for r in csv.DictReader(open(fs[0])):
-    k=r["Kernel_Name"].split("(")[0][-40:]
+    import re
+    m=re.search(r"(k_\w+)", r["Kernel_Name"]); k=m.group(1) if m else r["Kernel_Name"][:30]
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"]); 
     if r["Counter_Name"]=="$(echo $set | cut -d' ' -f1)": cnt[k]+=1
 for k,v in agg.items():

@@ -325,9 +325,10 @@ __device__ __forceinline__ CsRegion cs_cache_region(const uint32_t *__restrict__
 
 // meanShift + camShift (camshift.js:222-312) once the weight LUT is in LDS; every thread runs the identical scalar logic,
 // thread 0 writes the state.  NW = wavefronts of the workgroup.
-template <int NW>
-__device__ __forceinline__ void meanshift_body(const uint32_t *__restrict__ img, int W, int H, const double *lut, const CsRegion &R, double (*red)[NW], const int *s_sw,
-                                               HtCsState &st, int calc_angles, int max_it, ht_cs_trackobj *__restrict__ out_s, unsigned long long *stamps = nullptr) {
+// `moments(second, x, y, w, h)` computes camshift.Moments over the window for the whole workgroup (every thread gets the same Mom).
+template <typename MOMENTS>
+__device__ __forceinline__ void meanshift_body(int W, int H, const int *s_sw, HtCsState &st, int calc_angles, int max_it, ht_cs_trackobj *__restrict__ out_s,
+                                               unsigned long long *stamps, bool writer, MOMENTS moments) {
     int swx = s_sw[0], swy = s_sw[1];
     int n_stamp = 4;
     (void)n_stamp;
@@ -344,10 +345,10 @@ __device__ __forceinline__ void meanshift_body(const uint32_t *__restrict__ img,
         wadh = min(wady + swh, H);
         visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
         if (it == 9) {
-            m = window_moments_any<true, NW>(img, W, lut, R, wadx, wady, wadw, wadh, red);
+            m = moments(true, wadx, wady, wadw, wadh);
             have_second = true;
         } else {
-            m = window_moments_any<false, NW>(img, W, lut, R, wadx, wady, wadw, wadh, red, (stamps && it == 0) ? stamps + 16 : nullptr);
+            m = moments(false, wadx, wady, wadw, wadh);
         }
         CS_STAMP(stamps, n_stamp);
         n_stamp++;
@@ -358,7 +359,7 @@ __device__ __forceinline__ void meanshift_body(const uint32_t *__restrict__ img,
         if (it == 0) CS_STAMP(stamps, 23);
         if (swx == prevx && swy == prevy) {                                      // camshift.js:299-301
             if (!have_second) {
-                m = window_moments_any<true, NW>(img, W, lut, R, wadx, wady, wadw, wadh, red);
+                m = moments(true, wadx, wady, wadw, wadh);
                 visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
             }
             have_second = true;
@@ -368,7 +369,7 @@ __device__ __forceinline__ void meanshift_body(const uint32_t *__restrict__ img,
         prevy = swy;
     }
     CS_STAMP(stamps, n_stamp);
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0 || !writer) return;
     swx = max(0, min(swx, W));  // camshift.js:308-309
     swy = max(0, min(swy, H));
     const double invM00 = 1.0 / m.m00, xc = m.m10 * invM00, yc = m.m01 * invM00;
@@ -441,7 +442,9 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
     __syncthreads();
     const CsRegion R = cs_cache_region<CS_NT>(img, W, H, s_sw, reinterpret_cast<uint16_t *>(cs_dyn), region_cap);
     __syncthreads();
-    meanshift_body<CS_NT / 64>(img, W, H, lut, R, red, s_sw, st, calc_angles, max_it, out ? out + s : nullptr);
+    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, true, [&](bool second, int x, int y, int w, int h) {
+        return second ? window_moments_any<true, CS_NT / 64>(img, W, lut, R, x, y, w, h, red) : window_moments_any<false, CS_NT / 64>(img, W, lut, R, x, y, w, h, red);
+    });
 }
 
 // One launch per track() call when there are enough streams to fill the chip by themselves: ONE 1024-thread workgroup per stream
@@ -565,11 +568,149 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const uint8_t *__re
     if (!rows2d) R = cs_cache_region<FUSED_NT>(reinterpret_cast<const uint32_t *>(frame), W, H, s_sw, rbins, region_cap);
     __syncthreads();  // LUT and region complete
     CS_STAMP(stamps, 3);
-    meanshift_body<FUSED_NT / 64>(reinterpret_cast<const uint32_t *>(frame), W, H, lut, R, red, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, stamps);
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(frame);
+    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, stamps, true, [&](bool second, int x, int y, int w, int h) {
+        return second ? window_moments_any<true, FUSED_NT / 64>(img, W, lut, R, x, y, w, h, red) : window_moments_any<false, FUSED_NT / 64>(img, W, lut, R, x, y, w, h, red);
+    });
 #ifdef HT_CS_TIMELINE
     if (threadIdx.x == 0 && dbg_hist)
         for (int i = 0; i < 30; i++) reinterpret_cast<unsigned long long *>(dbg_hist + (size_t)s * 4096 + 4032)[i] = s_stamps[i];
 #endif
+}
+
+// ---- few large streams: a CLUSTER of workgroups per stream ---------------------------------------------------------------
+// One workgroup streams a window at one CU's memory rate: a 360 x 360 search window of a 1080p feed (130 k pixels, 0.5 MB per
+// pass) took ~30 us per pass, 146 us per track() call.  Here G workgroups share every pass (rows interleaved over all their
+// wavefronts), publish their six partial sums with agent-scope stores, arrive on a per-stream counter (zeroed by the host before
+// the launch) and read everybody's partials back once the counter shows all G arrivals — a counter barrier, ~3 us per
+// iteration (MI355X_MICROARCH.md price list), no agent-scope fences (payload and flag are sc1 / atomic both sides).  Every
+// workgroup sums the G partials in the same order, so all of them take identical mean-shift decisions; workgroup 0 writes the
+// state.  The grid (streams x G <= 256 workgroups) is always co-resident: the spin cannot starve a workgroup that has not started.
+constexpr int CL_NT = 512, CL_MAXG = 32, CL_SLOTS = 12;  // <= 11 moment passes per call (camshift.js:284-306)
+
+// weight LUT of every stream from its chunk histograms (getWeights, camshift.js:314-330): grid (64, streams) x 512 threads;
+// a block owns 64 bins, its 8 wavefronts each sum every 8th chunk (a single 1080p stream has 127 chunk histograms = 2 MB)
+__global__ __launch_bounds__(512) void k_cs_lut(const uint32_t *__restrict__ hist, int nchunks, const HtCsState *__restrict__ states, int first,
+                                                double *__restrict__ lut) {
+    __shared__ uint32_t part[8][64];
+    const int s = blockIdx.y, lane = threadIdx.x & 63, grp = threadIdx.x >> 6, bin = blockIdx.x * 64 + lane;
+    const uint32_t *cur = hist + (size_t)s * nchunks * 4096 + bin;
+    uint32_t ch = 0;
+#pragma unroll 4
+    for (int k = grp; k < nchunks; k += 8) ch += cur[(size_t)k * 4096];
+    part[grp][lane] = ch;
+    __syncthreads();
+    if (grp == 0) {
+        ch = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) ch += part[q][lane];
+        double p = 0.0;
+        if (ch != 0) {
+            p = (double)states[first + s].model[bin] / (double)ch;
+            p = p < 1.0 ? p : 1.0;
+        }
+        lut[(size_t)s * 4096 + bin] = p;
+    }
+}
+
+template <bool SECOND>
+__device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img, int W, const double *lut, int x, int y, int w, int h, double (*red)[CL_NT / 64],
+                                               double *s_part, int g, int G, double *__restrict__ parts, unsigned long long *__restrict__ counter, int slot) {
+    constexpr int NW = CL_NT / 64, nv = SECOND ? 6 : 3;
+    Mom m = {0, 0, 0, 0, 0, 0};
+    const int ww = w - x, hh = h - y;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (ww > 0 && hh > 0) {
+        for (int j = g * NW + wave; j < hh; j += G * NW) {  // a row per (workgroup, wavefront); 8 column chunks of the row in flight
+            double rs = 0.0, ts = 0.0, us = 0.0;
+            const uint32_t *rowp = img + (size_t)(y + j) * W + x;
+            for (int cb = 0; cb < ww; cb += 512) {
+                uint32_t px[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) px[u] = rowp[min(cb + 64 * u + lane, ww - 1)];  // clamped address, value masked below
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int c = cb + 64 * u + lane;
+                    const double val = c < ww ? lut[cs_bin(px[u])] : 0.0;
+                    const double vx = (double)c;
+                    rs += val;
+                    ts += vx * val;
+                    if (SECOND) us += vx * vx * val;
+                }
+            }
+            const double vy = (double)j;
+            m.m00 += rs;
+            m.m10 += ts;
+            m.m01 += vy * rs;
+            if (SECOND) {
+                m.m11 += vy * ts;
+                m.m20 += us;
+                m.m02 += vy * vy * rs;
+            }
+        }
+    }
+    double v[6] = {m.m00, m.m10, m.m01, m.m11, m.m20, m.m02};
+    __syncthreads();  // red[] / s_part[] may still be read from the previous pass
+#pragma unroll
+    for (int k = 0; k < nv; k++) {
+        const double sum = wave_sum_f64(v[k]);
+        if (lane == 0) red[k][wave] = sum;
+    }
+    __syncthreads();
+    // this workgroup's partial sums -> its slot of the exchange buffer; arrive; wait for all G; read everybody's
+    double *slot_parts = parts + (size_t)slot * CL_MAXG * 6;
+    if (threadIdx.x < nv) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < NW; q++) sum += red[threadIdx.x][q];
+        __hip_atomic_store(&slot_parts[g * 6 + threadIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < 64) {  // wavefront 0 issued the stores: drain them, then one arrival per workgroup
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long target = (unsigned long long)G * (unsigned long long)(slot + 1);
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < G * 6) s_part[threadIdx.x] = __hip_atomic_load(&slot_parts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < nv; k++) {
+        double sum = 0.0;
+        for (int q = 0; q < G; q++) sum += s_part[q * 6 + k];  // fixed order: every workgroup of the cluster gets the same bits
+        v[k] = sum;
+    }
+    m.m00 = v[0], m.m10 = v[1], m.m01 = v[2], m.m11 = v[3], m.m20 = v[4], m.m02 = v[5];
+    return m;
+}
+
+__global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H, const double *__restrict__ lut_g,
+                                                                HtCsState *__restrict__ states, int first, int calc_angles, int max_it, int G,
+                                                                double *__restrict__ parts, unsigned long long *__restrict__ counters,
+                                                                ht_cs_trackobj *__restrict__ out) {
+    __shared__ double lut[4096];
+    __shared__ double red[6][CL_NT / 64];
+    __shared__ double s_part[CL_MAXG * 6];
+    __shared__ int s_sw[4];
+    const int s = blockIdx.x / G, g = blockIdx.x - s * G;
+    HtCsState &st = states[first + s];
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)s * frame_stride);
+    {
+        const double2 *src = reinterpret_cast<const double2 *>(lut_g + (size_t)s * 4096);
+        for (int i = threadIdx.x; i < 2048; i += CL_NT) reinterpret_cast<double2 *>(lut)[i] = src[i];
+    }
+    if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
+    __syncthreads();
+    double *my_parts = parts + (size_t)s * CL_SLOTS * CL_MAXG * 6;
+    unsigned long long *ctr = counters + s;
+    int slot = 0;
+    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, g == 0, [&](bool second, int x, int y, int w, int h) {
+        const int sl = slot++;
+        return second ? cluster_moments<true>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, ctr, sl)
+                      : cluster_moments<false>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, ctr, sl);
+    });
 }
 
 }  // namespace
@@ -593,6 +734,16 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
     c->d_cs_out = nullptr;
     HT_HIP(c, hipMalloc(&c->d_cs_hist, sizeof(uint32_t) * 4096 * hist_max_chunks(nstreams) * (size_t)nstreams));
     HT_HIP(c, hipMalloc(&c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)nstreams));
+    // cluster mean-shift (few large streams): per stream a LUT, CL_SLOTS x CL_MAXG partial-sum slots and an arrival counter
+    if (c->d_cs_lut) (void)hipFree(c->d_cs_lut);
+    if (c->d_cs_parts) (void)hipFree(c->d_cs_parts);
+    if (c->d_cs_ctr) (void)hipFree(c->d_cs_ctr);
+    c->d_cs_lut = c->d_cs_parts = nullptr;
+    c->d_cs_ctr = nullptr;
+    const int ncl = std::min(nstreams, 64);  // the cluster path is only taken for <= 64 streams per call
+    HT_HIP(c, hipMalloc(&c->d_cs_lut, sizeof(double) * 4096 * (size_t)ncl));
+    HT_HIP(c, hipMalloc(&c->d_cs_parts, sizeof(double) * CL_SLOTS * CL_MAXG * 6 * (size_t)ncl));
+    HT_HIP(c, hipMalloc(&c->d_cs_ctr, sizeof(unsigned long long) * (size_t)ncl));
     c->cs_streams = nstreams;
     return HT_OK;
 }
@@ -639,7 +790,20 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
         hipLaunchKernelGGL(k_cs_hist, dim3(nchunks, n), dim3(HIST_NT), 0, c->stream, frames, frame_stride, npix, chunk_px, c->d_cs_hist);
         HT_HIP(c, hipGetLastError());
     }
-    {
+    // a few large frames: G workgroups per stream share every moment pass (k_cs_meanshift_cluster); otherwise one workgroup per stream
+    const int G = std::min(CL_MAXG, 256 / std::max(n, 1));
+    if (c->cs_cluster && n <= 64 && G >= 4 && npix >= c->cs_cluster_min_px && c->dbg_cs_iters > 0) {
+        {
+            HtProfScope ps(c, "cs_lut");
+            HT_HIP(c, hipMemsetAsync(c->d_cs_ctr, 0, sizeof(unsigned long long) * (size_t)n, c->stream));
+            hipLaunchKernelGGL(k_cs_lut, dim3(64, n), dim3(512), 0, c->stream, c->d_cs_hist, (int)nchunks, c->d_cs, first, c->d_cs_lut);
+            HT_HIP(c, hipGetLastError());
+        }
+        HtProfScope ps(c, "cs_meanshift");
+        hipLaunchKernelGGL(k_cs_meanshift_cluster, dim3(n * G), dim3(CL_NT), 0, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_lut, c->d_cs, first,
+                           calc_angles, c->dbg_cs_iters, G, c->d_cs_parts, c->d_cs_ctr, d_out);
+        HT_HIP(c, hipGetLastError());
+    } else {
         HtProfScope ps(c, "cs_meanshift");
         hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), (size_t)CS_REGION_CAP * 2, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_hist, (int)nchunks,
                            c->d_cs, first, calc_angles, c->dbg_cs_iters, c->cs_region_cap, d_out);

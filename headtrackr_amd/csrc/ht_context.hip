@@ -240,6 +240,8 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     if (const char *e = getenv("HT_DEBUG_DEEP_GRID")) c->deep_grid = std::max(1, atoi(e));
     if (const char *e = getenv("HT_DEBUG_CS_FUSED_MIN")) c->cs_fused_min_streams = std::max(1, atoi(e));
     if (getenv("HT_DEBUG_CS_KEEP_HIST")) c->cs_keep_hist = true;
+    if (const char *e = getenv("HT_DEBUG_CS_CLUSTER")) c->cs_cluster = atoi(e) != 0;
+    if (const char *e = getenv("HT_DEBUG_CS_CLUSTER_MINPX")) c->cs_cluster_min_px = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HT_DEBUG_CS_REGION")) c->cs_region_cap = std::min(40960, std::max(0, atoi(e)));
     if (const char *e = getenv("HT_DEBUG_CS_ITERS")) c->dbg_cs_iters = std::min(10, std::max(0, atoi(e)));
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
@@ -301,6 +303,9 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
     if (c->d_cs_seq_out) (void)hipFree(c->d_cs_seq_out);
+    if (c->d_cs_lut) (void)hipFree(c->d_cs_lut);
+    if (c->d_cs_parts) (void)hipFree(c->d_cs_parts);
+    if (c->d_cs_ctr) (void)hipFree(c->d_cs_ctr);
     if (c->d_gather) (void)hipFree(c->d_gather);
     for (auto &t : c->timers)
         for (auto &p : t.pending) (void)hipEventDestroy(p.first), (void)hipEventDestroy(p.second);

@@ -247,6 +247,10 @@ struct ht_ctx {
     HtCsState *d_cs = nullptr;
     uint32_t *d_cs_hist = nullptr;  // per-stream current-frame histogram (4096 bins)
     ht_cs_trackobj *d_cs_out = nullptr;
+    double *d_cs_lut = nullptr, *d_cs_parts = nullptr;  // cluster mean-shift: per-stream weight LUT, partial-sum exchange slots
+    unsigned long long *d_cs_ctr = nullptr;             // ... and arrival counters (zeroed before every launch)
+    bool cs_cluster = true;                              // HT_DEBUG_CS_CLUSTER=0 disables the cluster path
+    uint32_t cs_cluster_min_px = 400000;                 // frames at least this large take it (HT_DEBUG_CS_CLUSTER_MINPX)
     ht_cs_trackobj *d_cs_seq_out = nullptr;  // ht_camshift_track_sequence: [calls][streams] results, one D2H at the end
     size_t cs_seq_cap = 0;
     int cs_fused_min_streams = 192;  // >= this many streams per call: k_cs_track_fused (HT_DEBUG_CS_FUSED_MIN)

@@ -227,6 +227,7 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         const int v = atoi(e);
         if (v >= 1 && v <= HT_RS_MAX_PASSES) c->rs_rpt = v;
     }
+    if (const char *e = getenv("HT_DEBUG_RS_TAILTABLE")) c->tail_table = atoi(e) != 0;
     if (const char *e = getenv("HT_DEBUG_RS_MINWG")) c->rs_min_wgs = std::max(1, atoi(e));  // measurement knob
     if (const char *e = getenv("HT_DEBUG_RS_GROUP")) {  // measurement knob
         const int v = atoi(e);
@@ -273,6 +274,9 @@ static void free_geometry(ht_ctx *c) {
     if (c->d_tile_refs) (void)hipFree(c->d_tile_refs), c->d_tile_refs = nullptr;
     if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
     if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;
+    if (c->d_tail_taps) (void)hipFree(c->d_tail_taps), c->d_tail_taps = nullptr;
+    if (c->d_tail_taps_fast) (void)hipFree(c->d_tail_taps_fast), c->d_tail_taps_fast = nullptr;
+    if (c->d_tail_tapref) (void)hipFree(c->d_tail_tapref), c->d_tail_tapref = nullptr;
     c->tail_first_gen = 0;
     c->h_gens.clear();
     c->gen_blocks.clear();
@@ -331,6 +335,23 @@ static double ht_scale_pow(int interval, int i) {
 }
 
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+
+// rs_tap (ht_pyramid.hip) on the host: the same binary64 operations in the same order (this file is compiled with
+// -ffp-contract=off like the kernels, so nothing is fused)
+static HtTap ht_host_tap(int i, double r, int s, int origin) {
+    double f = ((double)i + 0.5) * r;
+    f = f + (-0.5);
+    f = f < 0.0 ? 0.0 : f;
+    const double fmax = (double)(s - 1);
+    f = f > fmax ? fmax : f;
+    const double af = std::floor(f);
+    HtTap tp;
+    tp.a = origin + (int)af;
+    tp.b = origin + std::min((int)af + 1, s - 1);
+    tp.t = f - af;
+    tp.u = 1.0 - tp.t;
+    return tp;
+}
 
 // Builds every table / allocation of one geometry.  On any failure the caller (ht_set_geometry) frees what was built and
 // leaves the context without a geometry, so a retry (e.g. with a smaller max_batch after HT_ERR_NOMEM) starts clean.
@@ -466,8 +487,14 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
     HT_HIP(c, hipMemset(c->d_arena, 0, c->arena_stride * (uint64_t)max_batch));
 
     // tail plan: from the first generation g0 on which every generation has <= HT_TAIL_MAX_JOBS jobs and all of them
-    // together <= 32768 destination pixels per frame, one workgroup per frame does the rest of the pyramid in one launch
-    // (k_resample_tail) instead of one nearly empty launch per generation
+    // together <= tail_cap destination pixels per frame, one workgroup per frame does the rest of the pyramid in one launch
+    // (k_resample_tail) instead of one nearly empty launch per generation.
+    const uint64_t tail_cap = getenv("HT_DEBUG_RS_TAILCAP") ? (uint64_t)atoll(getenv("HT_DEBUG_RS_TAILCAP")) : 32768u;
+    // which tail kernel: measured (3 batches in flight), the table-driven binary32 tail (68 VGPRs, 35 KB LDS) is worth +4-5 % at
+    // 128 x 720p but costs 3 % at 256 x 320x240, where its grid puts a 1024-thread workgroup on EVERY CU and its footprint keeps
+    // the other batches' kernels from sharing them; the round-1 binary64 tail (41 VGPRs) is kept for batches that cover the chip.
+    // Larger caps (generation 3 of C2 = 54 k pixels in the tail) lose with either kernel.
+    if (!getenv("HT_DEBUG_RS_TAILTABLE")) c->tail_table = max_batch <= 128;
     c->tail_first_gen = 0;
     if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
     if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;
@@ -477,7 +504,7 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
         for (int g = ngen - 1; g >= 1; g--) {
             uint64_t gp = 0;
             for (auto &j : c->h_gens[g]) gp += (uint64_t)j.cw * j.ch;
-            if (c->h_gens[g].size() > (size_t)HT_TAIL_MAX_JOBS || px + gp > 32768) break;
+            if (c->h_gens[g].size() > (size_t)HT_TAIL_MAX_JOBS || px + gp > tail_cap) break;
             px += gp;
             g0 = g;
         }
@@ -503,6 +530,35 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
                 HT_HIP(c, hipMemcpy(c->d_tail_jobs, tj.data(), tj.size() * sizeof(HtResampleJob), hipMemcpyHostToDevice));
                 HT_HIP(c, hipMalloc(&c->d_tail_prefix, pref.size() * sizeof(uint32_t)));
                 HT_HIP(c, hipMemcpy(c->d_tail_prefix, pref.data(), pref.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+                // tap tables: the geometry is the same for every frame, so the taps are computed once here
+                std::vector<HtTap> taps;
+                std::vector<HtTapFast> fast;
+                std::vector<HtTailTapRef> refs;
+                const bool nofast = getenv("HT_DEBUG_RS_NOFAST") != nullptr;
+                size_t jidx = 0;
+                for (auto &j : tj) {
+                    for (int g = 0; g <= T.ngen; g++)
+                        if ((size_t)T.job_begin[g] == jidx) T.tap_begin[g] = (uint32_t)taps.size();
+                    jidx++;
+                    HtTailTapRef r;
+                    r.col = (uint32_t)taps.size();
+                    const int ncol = std::max(j.dw, 1), nrow = std::max(j.dh, 1);
+                    for (int i = 0; i < ncol + 3; i++) taps.push_back(ht_host_tap(std::min(i, ncol - 1), j.rx, j.sw, j.sx));
+                    r.row = (uint32_t)taps.size();
+                    for (int i = 0; i < nrow; i++) taps.push_back(ht_host_tap(i, j.ry, j.sh, j.sy));
+                    r.mode = nofast ? 2u : ((j.dw > 0 && j.sw == 2 * j.dw && j.sh == 2 * j.dh) ? 1u : 0u);
+                    r.pad = 0;
+                    refs.push_back(r);
+                }
+                T.tap_begin[T.ngen] = (uint32_t)taps.size();
+                fast.resize(taps.size());
+                for (size_t i = 0; i < taps.size(); i++) fast[i].a = taps[i].a, fast[i].tf = (float)taps[i].t;
+                HT_HIP(c, hipMalloc(&c->d_tail_taps, taps.size() * sizeof(HtTap)));
+                HT_HIP(c, hipMemcpy(c->d_tail_taps, taps.data(), taps.size() * sizeof(HtTap), hipMemcpyHostToDevice));
+                HT_HIP(c, hipMalloc(&c->d_tail_taps_fast, fast.size() * sizeof(HtTapFast)));
+                HT_HIP(c, hipMemcpy(c->d_tail_taps_fast, fast.data(), fast.size() * sizeof(HtTapFast), hipMemcpyHostToDevice));
+                HT_HIP(c, hipMalloc(&c->d_tail_tapref, refs.size() * sizeof(HtTailTapRef)));
+                HT_HIP(c, hipMemcpy(c->d_tail_tapref, refs.data(), refs.size() * sizeof(HtTailTapRef), hipMemcpyHostToDevice));
                 c->tail_first_gen = g0;
             }
         }

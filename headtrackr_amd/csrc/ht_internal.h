@@ -89,6 +89,27 @@ struct HtTailGens {
     int32_t ngen;
     int32_t job_begin[HT_TAIL_MAX_GENS + 1];
     uint32_t groups[HT_TAIL_MAX_GENS];  // 4-pixel groups (canvas width rounded up to 4, times canvas height) per generation
+    uint32_t tap_begin[HT_TAIL_MAX_GENS + 1];  // range of the generation's entries in the tap tables (its jobs' taps are contiguous)
+};
+constexpr int HT_TAIL_LDS_TAPS = 4096;  // compact taps of one generation kept in LDS by k_resample_tail (32 KB)
+
+// One tap of the declared resampler (oracle/canvas_shim.js): destination coordinate i of a drawImage call reads source samples a
+// and b = min(a + 1, s - 1) (absolute, incl. the source rect origin) with weights u = 1 - t and t.  Computed on the device by
+// rs_tap (ht_pyramid.hip) and, for the tail kernel's jobs, once on the host by ht_host_tap — the same binary64 operations.
+struct HtTap {
+    double t, u;
+    int32_t a, b;
+};
+// k_resample_tail reads its taps from tables built by the host: the compact form {a, (float)t} for the binary32 estimate (column
+// tables are padded by 3 entries so that 4 consecutive ones can always be loaded), the full form for the rare binary64 fallback
+struct HtTapFast {
+    int32_t a;
+    float tf;
+};
+struct HtTailTapRef {
+    uint32_t col, row;  // first column / row tap of the job in both tables
+    uint32_t mode;      // bit 0: exact 2:1 in both directions (integer 2x2 box mean), bit 1: binary64 everywhere (HT_DEBUG_RS_NOFAST)
+    uint32_t pad;
 };
 
 // One drawImage call (host job list) and, with the tile fields filled in, one k_resample workgroup (device tile table).
@@ -203,8 +224,12 @@ struct ht_ctx {
     int tail_first_gen = 0;                  // first generation handled by the tail kernel (0 = none)
     HtResampleJob *d_tail_jobs = nullptr;    // jobs of generations >= tail_first_gen, generation by generation
     uint32_t *d_tail_prefix = nullptr;       // per job: 4-pixel groups of the jobs before it in its generation
+    HtTap *d_tail_taps = nullptr;            // tap tables of the tail jobs (full form) ...
+    HtTapFast *d_tail_taps_fast = nullptr;   // ... and compact form
+    HtTailTapRef *d_tail_tapref = nullptr;   // per tail job: where its taps start
     HtTailGens h_tail;                       // per generation: job range and group count (kernel argument)
     bool deep_attr_set = false;              // k_scan_deep_lds: > 64 KB dynamic LDS enabled on this context's device
+    bool tail_table = true;  // k_resample_tail with host tap tables (false: the round-1 binary64 tail, HT_DEBUG_RS_TAILTABLE=0)
     int rs_min_wgs = 2048;  // ... but never fewer workgroups per launch than this (HT_DEBUG_RS_MINWG)
     int rs_group = 8;  // k_resample: frames per workgroup at most (HT_DEBUG_RS_GROUP)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)

@@ -128,10 +128,7 @@ constexpr int RS_SP = 160;                  // LDS source tile: bytes per row (6
 // height decides how much of it is amortised: with 16 rows (1 row per thread) the 260k waves of one C2 generation run
 // in ~32 occupancy rounds of ~4 us each.
 
-struct RsTap {
-    double t, u;  // weights of b and a
-    int a, b;     // source coordinates (absolute, including the source rect origin)
-};
+typedef HtTap RsTap;  // {t, u: weights of b and a; a, b: source coordinates, absolute incl. the source rect origin}
 
 __device__ __forceinline__ RsTap rs_tap(int i, double r, int s, int origin) {
     double f = __dadd_rn(__dmul_rn((double)i + 0.5, r), -0.5);
@@ -417,8 +414,152 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
 // empty grids whose cost is launch + latency chain (C2: 48 us for 6 % of the pixels).  Here ONE workgroup per frame walks
 // those generations in order: a thread produces 4 destination pixels straight from HBM/L2 (own tap evaluation, no LDS
 // staging), generations are separated by a workgroup barrier.  Same arithmetic as k_resample's HBM-tap path.
-constexpr int TAIL_NT = 1024;
+#ifndef HT_TAIL_NT
+#define HT_TAIL_NT 1024
+#endif
+#ifndef HT_TAIL_U
+#define HT_TAIL_U 1  // groups per thread in flight: 1 = 68 VGPRs; 2-6 (96-240 VGPRs) measured no faster
+#endif
+constexpr int TAIL_NT = HT_TAIL_NT;
+// Taps come from tables the host built once per geometry (compact {a, (float)t} for the binary32 estimate, full binary64 form for the
+// fallback) and the pixels take the same binary32-estimate / integer-box-mean / binary64-fallback route as k_resample: the tail
+// used to spend ~135 binary64 instructions per group of 4 pixels on re-deriving taps and on the lerps.
 __global__ __launch_bounds__(TAIL_NT) void k_resample_tail(const HtResampleJob *__restrict__ jobs, const uint32_t *__restrict__ prefix,
+                                                          const HtTailTapRef *__restrict__ tapref, const HtTapFast *__restrict__ tfast,
+                                                          const HtTap *__restrict__ tfull, const HtTailGens G, uint8_t *__restrict__ arena,
+                                                          uint64_t arena_stride, uint32_t nframes) {
+    __shared__ HtResampleJob s_jobs[HT_TAIL_MAX_JOBS];
+    __shared__ HtTailTapRef s_ref[HT_TAIL_MAX_JOBS];
+    __shared__ uint32_t s_pref[HT_TAIL_MAX_JOBS + 1];
+    __shared__ HtTapFast s_taps[HT_TAIL_LDS_TAPS];  // the generation's compact taps: one global round trip less per group
+    uint32_t fidx, item;
+    if (!xcd_item(1u, nframes, &fidx, &item)) return;  // same frame -> XCD placement as the generations before
+    uint8_t *frame = arena + (uint64_t)fidx * arena_stride;
+    const int tid = (int)threadIdx.x;
+    for (int g = 0; g < G.ngen; g++) {
+        const int jb = G.job_begin[g], nj = G.job_begin[g + 1] - jb;
+        const uint32_t total = G.groups[g];
+        {
+            const uint32_t *src32 = reinterpret_cast<const uint32_t *>(jobs + jb);
+            uint32_t *dst32 = reinterpret_cast<uint32_t *>(s_jobs);
+            for (int i = tid; i < nj * (int)(sizeof(HtResampleJob) / 4); i += TAIL_NT) dst32[i] = src32[i];
+            if (tid < nj) s_pref[tid] = prefix[jb + tid], s_ref[tid] = tapref[jb + tid];
+            if (tid == 0) s_pref[nj] = total;
+        }
+        const uint32_t tap0 = G.tap_begin[g], ntap = G.tap_begin[g + 1] - tap0;
+        const bool taps_in_lds = ntap <= (uint32_t)HT_TAIL_LDS_TAPS;  // uniform
+        if (taps_in_lds)
+            for (uint32_t i = (uint32_t)tid; i < ntap; i += TAIL_NT) s_taps[i] = tfast[tap0 + i];
+        __syncthreads();
+        // TAIL_U groups per thread in flight: a group is a chain job lookup (LDS) -> taps (L2) -> source bytes (L2) -> store, and a
+        // thread that walks its groups one at a time pays that chain once per group (the late generations are pure latency);
+        // the phases below are separate loops over the TAIL_U groups so that every load of a phase is issued before the first use
+        constexpr int TAIL_U = HT_TAIL_U;
+        for (uint32_t i0 = (uint32_t)tid; i0 < total; i0 += TAIL_U * TAIL_NT) {
+            bool live[TAIL_U], draw[TAIL_U];
+            uint32_t doff[TAIL_U], mode[TAIL_U], tcol[TAIL_U], trow[TAIL_U];
+            int npx[TAIL_U], sstride[TAIL_U], dwm1[TAIL_U];
+            const uint8_t *sbase[TAIL_U];
+#pragma unroll
+            for (int u = 0; u < TAIL_U; u++) {  // phase 1: which job / row / columns
+                const uint32_t i = i0 + u * TAIL_NT;
+                live[u] = i < total;
+                const uint32_t ii = live[u] ? i : 0u;
+                int lo = 0, hi = nj;  // job of this group: last prefix <= i
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_pref[mid] <= ii) lo = mid;
+                    else hi = mid;
+                }
+                const HtResampleJob &J = s_jobs[lo];
+                const HtTailTapRef ref = s_ref[lo];
+                const uint32_t q = ii - s_pref[lo], qpr = (uint32_t)(J.cw + 3) >> 2;
+                const uint32_t y = q / qpr, x0 = (q - y * qpr) * 4u;
+                npx[u] = min(4, J.dw - (int)x0);
+                draw[u] = live[u] && (int)y < J.dh && npx[u] > 0;
+                doff[u] = J.dst_off + y * (uint32_t)J.dst_stride + x0;
+                mode[u] = ref.mode;
+                tcol[u] = ref.col + (draw[u] ? x0 : 0u);
+                trow[u] = ref.row + (draw[u] ? y : 0u);
+                sstride[u] = J.src_stride;
+                sbase[u] = frame + J.src_off;
+                dwm1[u] = max(J.dw - 1 - (int)x0, 0);
+            }
+            HtTapFast ctap[TAIL_U][4], rtap[TAIL_U];
+#pragma unroll
+            for (int u = 0; u < TAIL_U; u++) {  // phase 2: taps (the column table is padded: 4 entries are always loadable)
+                if (taps_in_lds) {
+                    const HtTapFast *cf = s_taps + (tcol[u] - tap0);
+                    ctap[u][0] = cf[0], ctap[u][1] = cf[1], ctap[u][2] = cf[2], ctap[u][3] = cf[3];
+                    rtap[u] = s_taps[trow[u] - tap0];
+                } else {
+                    const HtTapFast *cf = tfast + tcol[u];
+                    ctap[u][0] = cf[0], ctap[u][1] = cf[1], ctap[u][2] = cf[2], ctap[u][3] = cf[3];
+                    rtap[u] = tfast[trow[u]];
+                }
+            }
+            uint32_t p00[TAIL_U][4], p01[TAIL_U][4], p10[TAIL_U][4], p11[TAIL_U][4];
+#pragma unroll
+            for (int u = 0; u < TAIL_U; u++) {  // phase 3: source bytes.  b == a + 1 unless the coordinate was clamped to the rect's last
+                // sample, and then its weight is exactly 0: the second tap is then read at a itself, so no load ever leaves the source
+                // rect (the no-stale-L1 argument below needs every read to hit an already finished plane)
+                const uint8_t *r0 = sbase[u] + (size_t)rtap[u].a * sstride[u], *r1 = r0 + (rtap[u].tf != 0.0f ? sstride[u] : 0);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int ca = ctap[u][k].a, cb = ca + (ctap[u][k].tf != 0.0f ? 1 : 0);
+                    p00[u][k] = r0[ca], p01[u][k] = r0[cb], p10[u][k] = r1[ca], p11[u][k] = r1[cb];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TAIL_U; u++) {  // phase 4: pixels + store
+                uint32_t o = 0;
+                if (draw[u]) {
+                    auto exact64 = [&](int k) {  // the declared binary64 sequence with the full taps (b explicit: clamped at the rect's edge)
+                        const HtTap cx = tfull[tcol[u] + min(k, dwm1[u])], ry = tfull[trow[u]];
+                        const uint8_t *s0 = sbase[u] + (size_t)ry.a * sstride[u], *s1 = sbase[u] + (size_t)ry.b * sstride[u];
+                        const double top = __dadd_rn(__dmul_rn((double)s0[cx.a], cx.u), __dmul_rn((double)s0[cx.b], cx.t));
+                        const double bot = __dadd_rn(__dmul_rn((double)s1[cx.a], cx.u), __dmul_rn((double)s1[cx.b], cx.t));
+                        const double vv = __dadd_rn(__dmul_rn(top, ry.u), __dmul_rn(bot, ry.t));
+                        return (uint32_t)(int)__builtin_rint(vv);
+                    };
+                    uint32_t need = 0, obox = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t sum = p00[u][k] + p01[u][k] + p10[u][k] + p11[u][k], qq = sum >> 2, r4 = sum & 3u;
+                        obox |= (qq + ((r4 + (qq & 1u)) > 2u ? 1u : 0u)) << (8 * k);  // exact 2:1: RNE(sum / 4)
+                        const float a00 = (float)p00[u][k], a10 = (float)p10[u][k];
+                        const float top = __builtin_fmaf(ctap[u][k].tf, (float)p01[u][k] - a00, a00);
+                        const float bot = __builtin_fmaf(ctap[u][k].tf, (float)p11[u][k] - a10, a10);
+                        const float v = __builtin_fmaf(rtap[u].tf, bot - top, top);
+                        const float r = __builtin_rintf(v);
+                        if (__builtin_fabsf(v - r) >= 0.5f - RS_EPS) need |= 1u << k;
+                        o |= (uint32_t)(int)r << (8 * k);
+                    }
+                    const uint32_t keep = npx[u] >= 4 ? 0xffffffffu : ((1u << (8 * npx[u])) - 1u);
+                    if (mode[u] & 1u) o = obox, need = 0;
+                    if (mode[u] & 2u) need = 0xfu;  // HT_DEBUG_RS_NOFAST: binary64 everywhere
+                    need &= (1u << npx[u]) - 1u;
+                    o &= keep;
+                    if (need) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (need & (1u << k)) o = (o & ~(0xffu << (8 * k))) | (exact64(k) << (8 * k));
+                    }
+                }
+                if (live[u]) *reinterpret_cast<uint32_t *>(frame + doff[u]) = o;  // incl. the transparent border
+            }
+        }
+        // the next generation reads what this workgroup just wrote: a workgroup-scope barrier is enough — the stores are
+        // complete in L2 (write-through L1) before the barrier releases, and this CU cannot hold a stale L1 copy of a
+        // destination line (nothing reads a plane before the generation that writes it; planes are 256-byte aligned).
+        // Agent-scope fences here cost 4x the whole kernel: buffer_wbl2 writes the XCD's entire dirty L2 back.
+        __syncthreads();
+    }
+}
+
+// the round-1 tail kernel: taps re-derived per group in registers, binary64 lerps (kept for A/B: HT_DEBUG_RS_TAILTABLE=0)
+constexpr int TAILF_NT = 1024;
+__global__ __launch_bounds__(TAILF_NT) void k_resample_tail_f64(const HtResampleJob *__restrict__ jobs, const uint32_t *__restrict__ prefix,
                                                           const HtTailGens G, uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                           uint32_t nframes) {
     __shared__ HtResampleJob s_jobs[HT_TAIL_MAX_JOBS];
@@ -433,12 +574,12 @@ __global__ __launch_bounds__(TAIL_NT) void k_resample_tail(const HtResampleJob *
         {
             const uint32_t *src32 = reinterpret_cast<const uint32_t *>(jobs + jb);
             uint32_t *dst32 = reinterpret_cast<uint32_t *>(s_jobs);
-            for (int i = tid; i < nj * (int)(sizeof(HtResampleJob) / 4); i += TAIL_NT) dst32[i] = src32[i];
+            for (int i = tid; i < nj * (int)(sizeof(HtResampleJob) / 4); i += TAILF_NT) dst32[i] = src32[i];
             if (tid < nj) s_pref[tid] = prefix[jb + tid];
             if (tid == 0) s_pref[nj] = total;
         }
         __syncthreads();
-        for (uint32_t i = (uint32_t)tid; i < total; i += TAIL_NT) {
+        for (uint32_t i = (uint32_t)tid; i < total; i += TAILF_NT) {
             int lo = 0, hi = nj;  // job of this group: last prefix <= i
             while (hi - lo > 1) {
                 const int mid = (lo + hi) >> 1;
@@ -545,8 +686,12 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
     }
     if (c->tail_first_gen > 0) {
         HtProfScope ps(c, "resample");
-        hipLaunchKernelGGL(k_resample_tail, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
-                           c->h_tail, c->d_arena, c->arena_stride, (uint32_t)c->nframes);
+        if (c->tail_table)
+            hipLaunchKernelGGL(k_resample_tail, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
+                               c->d_tail_tapref, c->d_tail_taps_fast, c->d_tail_taps, c->h_tail, c->d_arena, c->arena_stride, (uint32_t)c->nframes);
+        else
+            hipLaunchKernelGGL(k_resample_tail_f64, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAILF_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
+                               c->h_tail, c->d_arena, c->arena_stride, (uint32_t)c->nframes);
         HT_HIP(c, hipGetLastError());
     }
     return HT_OK;

@@ -146,6 +146,20 @@ def test_gray_in_r_entry(ctx, cascade):
     assert len(a) == 9 and a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("table", ["0", "1"], ids=["binary64-tail", "table-tail"])
+@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (38, 30)])
+def test_pyramid_both_tail_kernels(w, h, table, monkeypatch):
+    """The last generations are built by one of two tail kernels, chosen by batch size: the round-1 one (taps re-derived in
+    registers, binary64 lerps) and the table-driven one (host tap tables, binary32 estimate + binary64 fallback, integer box
+    means).  Forced here on the same inputs: every plane equals the oracle's with either."""
+    monkeypatch.setenv("HT_DEBUG_RS_TAILTABLE", table)
+    c = Context()
+    try:
+        _check_pyramid(c, w, h)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (1280, 720)])
 def test_pyramid_fast_paths_equal_the_declared_binary64_sequence(w, h, monkeypatch):
     """k_resample evaluates a pixel in binary32 and falls back to the declared binary64 sequence next to a rounding boundary;

@@ -23,7 +23,7 @@ ht_status ht_fail(ht_ctx *ctx, ht_status st, const std::string &msg) {
     return st;
 }
 
-HtProfScope::HtProfScope(ht_ctx *c, const char *name) : ctx(c) {
+HtProfScope::HtProfScope(ht_ctx *c, const char *name, hipStream_t on) : ctx(c), stream(on ? on : c->stream) {
     if (!ctx->profiling) return;
     for (size_t i = 0; i < ctx->timers.size(); i++)
         if (ctx->timers[i].name == name) idx = (int)i;
@@ -36,11 +36,11 @@ HtProfScope::HtProfScope(ht_ctx *c, const char *name) : ctx(c) {
         idx = -1;
         return;
     }
-    (void)hipEventRecord(a, ctx->stream);
+    (void)hipEventRecord(a, stream);
 }
 HtProfScope::~HtProfScope() {
     if (idx < 0) return;
-    (void)hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, stream);
     ctx->timers[idx].pending.emplace_back(a, b);
     ctx->timers[idx].launches++;
 }
@@ -228,6 +228,14 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         if (v >= 1 && v <= HT_RS_MAX_PASSES) c->rs_rpt = v;
     }
     if (const char *e = getenv("HT_DEBUG_RS_TAILTABLE")) c->tail_table = atoi(e) != 0;
+    if (const char *e = getenv("HT_DEBUG_EARLY_SCAN")) c->early_scan = atoi(e) != 0;
+    if (c->early_scan) {
+        if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_early_ready, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->ev_early_done, hipEventDisableTiming) != hipSuccess) {
+            c->err = "hipStreamCreate (aux) failed";
+            return bail(HT_ERR_HIP);
+        }
+    }
     if (const char *e = getenv("HT_DEBUG_RS_MINWG")) c->rs_min_wgs = std::max(1, atoi(e));  // measurement knob
     if (const char *e = getenv("HT_DEBUG_RS_GROUP")) {  // measurement knob
         const int v = atoi(e);
@@ -287,6 +295,9 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream), (void)hipStreamDestroy(c->aux_stream);
+    if (c->ev_early_ready) (void)hipEventDestroy(c->ev_early_ready);
+    if (c->ev_early_done) (void)hipEventDestroy(c->ev_early_done);
     free_geometry(c);
     if (c->d_tile_feats) (void)hipFree(c->d_tile_feats);
     if (c->d_deep_feats) (void)hipFree(c->d_deep_feats);
@@ -566,6 +577,18 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
 
     ht_status st = ht_scan_plan_tiles(c);
     if (st != HT_OK) return st;
+    // early scan plan: scale i needs levels i, i + next, i + 2 next; the leading scales whose last plane is finished after
+    // generation 2 (interval 5: scale 0 = ~30 % of the windows) can start while generations 3.. are still being built
+    c->early_gen = 0;
+    c->early_tiles = 0;
+    if (c->early_scan && c->aux_stream && ngen > 3 && (c->tail_first_gen == 0 || c->tail_first_gen > 2)) {
+        uint32_t tiles = 0;
+        for (auto &S : c->h_scales) {
+            if (gen[S.l2] > 2) break;
+            tiles += (uint32_t)(S.ntx * S.nty);
+        }
+        if (tiles > 0 && tiles < c->tiles_per_frame) c->early_gen = 2, c->early_tiles = tiles;
+    }
 
     // survivor queue between the tile kernel and the deep kernel: 1/8 of all windows unless configured
     uint64_t qc = c->queue_capacity_cfg ? c->queue_capacity_cfg : std::max<uint64_t>(1u << 16, c->windows_per_frame * (uint64_t)max_batch / 8);
@@ -736,6 +759,7 @@ extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
     if (!c->d_frames || c->nframes <= 0) return ht_fail(c, HT_ERR_STATE, "ht_detect_enqueue: no frames bound");
     HT_HIP(c, hipSetDevice(c->device));
     HT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(HtCounters), c->stream));
+    c->early_launched = false;
     c->stats_enqueued = (flags & HT_SCAN_STATS) != 0;
     if (c->stats_enqueued) HT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS, c->stream));
     ht_status st;

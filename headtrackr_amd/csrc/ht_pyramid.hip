@@ -683,6 +683,10 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,
                            c->gen_blocks[g], ngroups, (uint32_t)c->nframes, K);
         HT_HIP(c, hipGetLastError());
+        if ((int)g == c->early_gen && c->early_gen > 0) {  // the early scales' planes are complete: their scan starts on the second stream
+            ht_status st = ht_launch_scan_early(c, flags);
+            if (st != HT_OK) return st;
+        }
     }
     if (c->tail_first_gen > 0) {
         HtProfScope ps(c, "resample");

@@ -1113,6 +1113,43 @@ ht_status ht_scan_plan_tiles(ht_ctx *c) {
     return HT_OK;
 }
 
+// tile kernel over tiles [first, first + count) of every frame's tile list, on `stream`
+static ht_status launch_tiles(ht_ctx *c, uint32_t flags, hipStream_t stream, uint32_t first, uint32_t count) {
+    unsigned long long *stats = (flags & HT_SCAN_STATS) ? c->d_stats : nullptr;
+    const int split = (flags & HT_SCAN_NO_SPLIT) ? (int)c->nstages : (int)std::min<uint32_t>(c->split_stage, c->nstages);
+    const uint64_t total64 = (uint64_t)count * (uint64_t)c->nframes;
+    if (total64 > 0x7fffff00ull) return ht_fail(c, HT_ERR_INVALID, "ht_detect: batch too large for one launch");
+    const uint32_t total = (uint32_t)total64;
+    const bool gen = c->builtin_cascade && !(flags & HT_SCAN_GENERIC);
+    // measurement knob: stop the tile kernel before a stage; test knob: treat every integer stage decision as an exact tie,
+    // i.e. always take the sequential-binary64 fallback (both read from the environment once, in ht_create)
+    const int stop_stage = c->dbg_stop_stage, force_exact = c->dbg_force_exact;
+    HtProfScope ps(c, "scan_tiles", stream);
+    if (gen)
+        hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, stream, c->d_arena, c->arena_stride, c->d_levels, c->d_scales,
+                           c->d_tile_refs + first, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
+                           c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
+    else
+        hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, stream, c->d_arena, c->arena_stride, c->d_levels, c->d_scales,
+                           c->d_tile_refs + first, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
+                           c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
+    HT_HIP(c, hipGetLastError());
+    return HT_OK;
+}
+
+// Called by ht_launch_pyramid right after the generation that completes the early scales' planes: their tiles are scanned on the
+// second stream while the main stream builds the remaining small generations (which are latency-, not throughput-bound).
+ht_status ht_launch_scan_early(ht_ctx *c, uint32_t flags) {
+    if (c->early_tiles == 0 || !c->aux_stream || (flags & HT_SCAN_SIMPLE) || c->cw != 24 || c->ch != 24) return HT_OK;
+    HT_HIP(c, hipEventRecord(c->ev_early_ready, c->stream));
+    HT_HIP(c, hipStreamWaitEvent(c->aux_stream, c->ev_early_ready, 0));
+    ht_status st = launch_tiles(c, flags, c->aux_stream, 0, c->early_tiles);
+    if (st != HT_OK) return st;
+    HT_HIP(c, hipEventRecord(c->ev_early_done, c->aux_stream));
+    c->early_launched = true;
+    return HT_OK;
+}
+
 ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     if (c->h_scales.empty() || c->tiles_per_frame == 0) return HT_OK;  // image too small for any window
     const int nscales = (int)c->h_scales.size();
@@ -1128,24 +1165,12 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
         return HT_OK;
     }
     const int split = (flags & HT_SCAN_NO_SPLIT) ? (int)c->nstages : (int)std::min<uint32_t>(c->split_stage, c->nstages);
-    const uint64_t total64 = (uint64_t)c->tiles_per_frame * (uint64_t)c->nframes;
-    if (total64 > 0x7fffff00ull) return ht_fail(c, HT_ERR_INVALID, "ht_detect: batch too large for one launch");
-    const uint32_t total = (uint32_t)total64;
-    const bool gen = c->builtin_cascade && !(flags & HT_SCAN_GENERIC);
-    // measurement knob: stop the tile kernel before a stage; test knob: treat every integer stage decision as an exact tie,
-    // i.e. always take the sequential-binary64 fallback (both read from the environment once, in ht_create)
-    const int stop_stage = c->dbg_stop_stage, force_exact = c->dbg_force_exact;
+    const int force_exact = c->dbg_force_exact;
     {
-        HtProfScope ps(c, "scan_tiles");
-        if (gen)
-            hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                               c->d_scales, c->d_tile_refs, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, c->tiles_per_frame,
-                               total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
-        else
-            hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, c->stream, c->d_arena, c->arena_stride, c->d_levels,
-                               c->d_scales, c->d_tile_refs, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, c->tiles_per_frame,
-                               total, c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
-        HT_HIP(c, hipGetLastError());
+        const uint32_t first = c->early_launched ? c->early_tiles : 0u;
+        ht_status st = launch_tiles(c, flags, c->stream, first, c->tiles_per_frame - first);
+        if (st != HT_OK) return st;
+        if (c->early_launched) HT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_early_done, 0));  // the deep kernel needs every tile's survivors
     }
     if (split < (int)c->nstages) {
         HtProfScope ps(c, "scan_deep");

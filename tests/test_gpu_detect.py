@@ -218,6 +218,21 @@ def test_full_batch_is_frame_independent(ctx, cascade):
     assert sum(int(counts[i] > 0) for i in range(2, n, 3)) > n // 3 * 0.9
 
 
+def test_early_scan_on_second_stream(cascade, monkeypatch):
+    """HT_DEBUG_EARLY_SCAN=1: scale 0 is scanned on a second HIP stream while the late pyramid generations are built; same hits
+    (two tile launches + event dependencies instead of one launch)."""
+    frames = synth.mixed_batch(12, 320, 240, seed0=1234)
+    monkeypatch.setenv("HT_DEBUG_EARLY_SCAN", "1")
+    c = Context()
+    try:
+        for _ in range(3):  # back-to-back batches on one context: the next batch must not overtake the second stream
+            hits, _ = c.detect_raw(frames)
+        ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(12)])
+        assert_hits_equal(hits, ref)
+    finally:
+        c.close()
+
+
 def test_tiny_hit_capacity_reports_overflow(cascade):
     from headtrackr_amd.api import HtError
 

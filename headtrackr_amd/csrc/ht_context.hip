@@ -279,7 +279,7 @@ static void free_geometry(ht_ctx *c) {
     for (auto p : c->d_gen_blocks)
         if (p) (void)hipFree(p);
     c->d_gen_blocks.clear();
-    if (c->d_tile_refs) (void)hipFree(c->d_tile_refs), c->d_tile_refs = nullptr;
+    if (c->d_tile_recs) (void)hipFree(c->d_tile_recs), c->d_tile_recs = nullptr;
     if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
     if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;
     if (c->d_tail_taps) (void)hipFree(c->d_tail_taps), c->d_tail_taps = nullptr;
@@ -859,6 +859,7 @@ extern "C" ht_status ht_pyramid_readback(ht_ctx *c, int32_t frame, int32_t level
 extern "C" ht_status ht_stage_counts(ht_ctx *c, uint64_t *counts, int32_t n) {
     if (!c || !counts || n < (int32_t)c->nstages + 1) return HT_ERR_INVALID;
     for (uint32_t j = 0; j <= c->nstages; j++) counts[j] = c->h_stage_in[j];
+    for (int32_t j = (int32_t)c->nstages + 1; j < std::min<int32_t>(n, 64); j++) counts[j] = c->h_stage_in[j];  // raw counter row (timeline builds)
     return HT_OK;
 }
 

@@ -144,6 +144,20 @@ struct HtBlockRef {
     uint16_t pad;     // resample: number of 16-row passes in this tile; scan: unused
 };
 
+// Everything a k_scan_tiles workgroup needs to know about its tile in one 64-byte record = ONE scalar load after the tile index is
+// known (it used to be a chain of three dependent lookups — tile -> scale -> three level records — in front of the tile's first
+// HBM load; a workgroup holds its 26 KB of LDS while it waits).
+struct alignas(64) HtTileRec {
+    uint32_t off0, off1, off2[4];  // byte offsets inside a frame's arena: level i, level i+6, the four variants of level i+12
+    uint32_t sh0, sh1, sh2;        // stride | height << 16 of the three levels
+    uint32_t origin;               // X0 | Y0 << 16: tile origin in half-window steps
+    uint32_t size;                 // tw | th << 16: half-window steps of the tile that hold windows (clipped to the scale)
+    uint32_t tw2_l0;               // tile pitch tw2 (window id = Y' * tw2 + X') | the scale's level index << 16
+    uint32_t div_magic;            // ceil(2^20 / tw2)
+    uint32_t pad[3];
+};
+static_assert(sizeof(HtTileRec) == 64, "HtTileRec");
+
 // Survivor handed from the tile kernel to the deep kernel.
 struct HtQueueEntry {
     uint32_t frame;
@@ -225,7 +239,7 @@ struct ht_ctx {
     uint8_t *d_arena = nullptr;
     std::vector<std::vector<HtResampleJob>> h_gens;  // generation g: jobs that only depend on generations < g
     std::vector<HtResampleJob *> d_gen_blocks;  // per generation: k_resample tile records (job + tile position)
-    HtBlockRef *d_tile_refs = nullptr;        // per-frame tile -> (scale, tx, ty)
+    HtTileRec *d_tile_recs = nullptr;         // per-frame tile list (same for every frame of a batch)
     std::vector<uint32_t> gen_blocks;
     std::vector<HtScanScale> h_scales;
     HtScanScale *d_scales = nullptr;

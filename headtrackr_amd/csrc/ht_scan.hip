@@ -133,10 +133,27 @@ __device__ __forceinline__ double eval_stage_lds(const uint8_t *lds, uint32_t B,
     return sum;
 }
 
+// -DHT_TILE_TIMELINE (tools/gpu_tile_timeline.py): shader-clock time a workgroup spends in each phase, summed per phase into the
+// statistics rows (entries 32.. = cycles, 48.. = workgroups that went through the phase); needs HT_SCAN_STATS at run time
+#ifdef HT_TILE_TIMELINE
+#define TL_STAMP(p)                                                                              \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (my_stats && tid == 0) {                                                              \
+            const unsigned long long now_ = __builtin_readcyclecounter();                        \
+            atomicAdd(&my_stats[32 + (p)], now_ - tl_prev);                                      \
+            atomicAdd(&my_stats[48 + (p)], 1ull);                                                \
+            tl_prev = now_;                                                                      \
+        }                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
+#else
+#define TL_STAMP(p)
+#endif
+
 template <bool GEN>
 __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
-                                                   const HtDevLevel *__restrict__ levels, const HtScanScale *__restrict__ scales,
-                                                   const HtBlockRef *__restrict__ tile_refs, const HtTileFeature *__restrict__ feats,
+                                                   const HtTileRec *__restrict__ tile_recs, const HtTileFeature *__restrict__ feats,
                                                    const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,
                                                    int stop_stage, int force_exact, uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
                                                    uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
@@ -172,17 +189,22 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     const uint32_t t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
     if (t >= total_tiles) return;
     const uint32_t frame = t / tiles_per_frame, lt = t - frame * tiles_per_frame;
-    const HtBlockRef ref = tile_refs[lt];  // tile -> (scale, tile x, tile y): one scalar load
-    const HtScanScale S = scales[ref.item];
-    const int tyi = (int)ref.by, txi = (int)ref.bx;
-    const int X0 = txi * S.tw2, Y0 = tyi * S.th2;           // tile origin in half-window steps
-    const int tw = min(S.tw2, 2 * S.qw - X0), th = min(S.th2, 2 * S.qh - Y0);
-    const HtDevLevel L0 = levels[S.l0], L1 = levels[S.l1], L2 = levels[S.l2];
+    const HtTileRec R = tile_recs[lt];  // one 64-byte scalar load: everything about the tile
+    const int X0 = (int)(R.origin & 0xffffu), Y0 = (int)(R.origin >> 16);  // tile origin in half-window steps
+    const int tw = (int)(R.size & 0xffffu), th = (int)(R.size >> 16);
+    const struct { int tw2; uint32_t div_magic; uint32_t l0; } S = {(int)(R.tw2_l0 & 0xffffu), R.div_magic, R.tw2_l0 >> 16};
+    struct Plane { uint32_t off[4]; int stride, h; };
+    const Plane L0 = {{R.off0, 0u, 0u, 0u}, (int)(R.sh0 & 0xffffu), (int)(R.sh0 >> 16)};
+    const Plane L1 = {{R.off1, 0u, 0u, 0u}, (int)(R.sh1 & 0xffffu), (int)(R.sh1 >> 16)};
+    const Plane L2 = {{R.off2[0], R.off2[1], R.off2[2], R.off2[3]}, (int)(R.sh2 & 0xffffu), (int)(R.sh2 >> 16)};
     const uint8_t *fbase = arena + (uint64_t)frame * arena_stride;
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     // optional survival statistics: one of HT_STAT_SHARDS counter rows per workgroup (same-address atomics from 15k
     // workgroups serialise in L2 at ~90/us, which would dominate the kernel)
     unsigned long long *my_stats = stats ? stats + (size_t)(blockIdx.x & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
+#ifdef HT_TILE_TIMELINE
+    unsigned long long tl_prev = __builtin_readcyclecounter();
+#endif
 
     // ---- stage the three planes into LDS --------------------------------------------------------------------
     // All global loads of a thread are issued before the first LDS write (fixed trip counts, predicated), so one
@@ -192,50 +214,52 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     // VALU instructions, most of it address arithmetic and predicates per load.  Chunks may run past a row's end into
     // the next row / plane of the same arena; those bytes land in LDS columns no window of the tile reads.
     {
-        // plane 0: level i, origin (2*X0, 2*Y0), PITCH0 bytes per row
-        const uint8_t *p0 = fbase + L0.off[0];
+        // plane 0: level i, origin (2*X0, 2*Y0), PITCH0 bytes per row.  Addresses are the frame's (wave-uniform) base + a 32-bit
+        // per-thread offset, and a chunk that is not needed is neither loaded nor written (its LDS bytes keep whatever the
+        // previous tile left there: no valid window reads them) — staging used to be 23 % of the kernel's VALU instructions,
+        // half of them 64-bit address arithmetic and zero-initialisation of the predicated loads.
         const int gx0 = 2 * X0, gy0 = 2 * Y0;
         constexpr int C0 = (PITCH0 + 15) / 16;  // 16-byte chunks per row; with PITCH0 % 16 == 8 the last one is half a chunk
         const int n0 = (2 * th + 22) * C0;
         constexpr int K0 = (ROWS0 * C0 + NT - 1) / NT;
         uint4 v0[K0];
+        bool ok0[K0];
 #pragma unroll
         for (int k = 0; k < K0; k++) {
             const int i = (int)tid + k * NT;
             const int r = i / C0, c16 = (i - r * C0) * 16;
             const int gy = gy0 + r, gx = gx0 + c16;
-            v0[k] = make_uint4(0u, 0u, 0u, 0u);
-            if (i < n0 && gy < L0.h && gx < L0.stride) v0[k] = *reinterpret_cast<const uint4 *>(p0 + (size_t)gy * L0.stride + gx);
+            ok0[k] = i < n0 && gy < L0.h && gx < L0.stride;
+            if (ok0[k]) v0[k] = *reinterpret_cast<const uint4 *>(fbase + (L0.off[0] + (uint32_t)__mul24(gy, L0.stride) + (uint32_t)gx));
         }
         // planes 1 + 2: half-step grid cell (X, Y) = { level i+6 pixel (X0+X, Y0+Y),  variant q pixel ((X0+X)>>1, (Y0+Y)>>1) }
         // with q = ((Y0+Y)&1)*2 + ((X0+X)&1)   (ccv.js:132-146: variant q is level i+6 shifted by (dx,dy) then halved).
-        // A thread builds 8 consecutive cells from 8 bytes of level i+6 and 4 bytes of each of the two variants.
-        const uint8_t *p1 = fbase + L1.off[0];
+        // A thread builds 8 consecutive cells from 8 bytes of level i+6 and 4 bytes of each of the two variants (coordinates
+        // clamped into the variant's plane: cells beyond it belong to no window).
         constexpr int GG = (TXH + 11 + 7) / 8;  // cell groups per row (10)
         const int n12 = (th + 11) * GG;
         constexpr int K12 = (GH * GG + NT - 1) / NT;
         uint2 va[K12];
         uint32_t vb[K12], vc[K12];
+        bool ok12[K12];
 #pragma unroll
         for (int k = 0; k < K12; k++) {
             const int g = (int)tid + k * NT;
             const int Y = g / GG, Xg = (g - Y * GG) * 8;
-            const int ay = Y0 + Y, ax = X0 + Xg, y2 = ay >> 1, x2 = ax >> 1;
+            const int ay = Y0 + Y, ax = X0 + Xg, y2 = min(ay >> 1, L2.h - 1), x2 = min(ax >> 1, L2.stride - 4);
             const uint32_t o2a = (ay & 1) ? L2.off[2] : L2.off[0], o2b = (ay & 1) ? L2.off[3] : L2.off[1];
-            va[k] = make_uint2(0u, 0u);
-            vb[k] = vc[k] = 0;
-            if (g < n12) {
-                if (ay < L1.h && ax < L1.stride) va[k] = *reinterpret_cast<const uint2 *>(p1 + (size_t)ay * L1.stride + ax);
-                if (y2 < L2.h && x2 < L2.stride) {
-                    vb[k] = *reinterpret_cast<const uint32_t *>(fbase + o2a + (size_t)y2 * L2.stride + x2);
-                    vc[k] = *reinterpret_cast<const uint32_t *>(fbase + o2b + (size_t)y2 * L2.stride + x2);
-                }
+            ok12[k] = g < n12 && ay < L1.h && ax < L1.stride;
+            if (ok12[k]) {
+                const uint32_t o2 = (uint32_t)__mul24(y2, L2.stride) + (uint32_t)x2;
+                va[k] = *reinterpret_cast<const uint2 *>(fbase + (L1.off[0] + (uint32_t)__mul24(ay, L1.stride) + (uint32_t)ax));
+                vb[k] = *reinterpret_cast<const uint32_t *>(fbase + (o2a + o2));
+                vc[k] = *reinterpret_cast<const uint32_t *>(fbase + (o2b + o2));
             }
         }
 #pragma unroll
         for (int k = 0; k < K0; k++) {
             const int i = (int)tid + k * NT;
-            if (i < n0) {
+            if (ok0[k]) {
                 if (PITCH0 % 16 == 0) {
                     *reinterpret_cast<uint4 *>(&lds[i * 16]) = v0[k];  // rows are contiguous: r*PITCH0 + c16 == i*16
                 } else {  // rows are 8-byte aligned: two 8-byte halves, the second one dropped where it would spill into the next row
@@ -249,7 +273,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 #pragma unroll
         for (int k = 0; k < K12; k++) {
             const int g = (int)tid + k * NT;
-            if (g < n12) {
+            if (ok12[k]) {
                 const int Y = g / GG, Xg = (g - Y * GG) * 8;
                 const uint32_t b = vb[k], c = vc[k];
                 // cell j = { a_j, (j even ? b : c)_{j/2} }: v_perm_b32 picks bytes from {src0 = bytes 4-7, src1 = bytes 0-3}
@@ -264,6 +288,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     }
     if (tid == 0) s_nout = 0;
     __syncthreads();
+    TL_STAMP(0);
 
     // ---- cascade with per-stage compaction -------------------------------------------------------------------
     uint32_t n_in = (uint32_t)(S.tw2 * th);  // stage 0 enumerates id = Y'*tw2 + X' (X' >= tw is masked off)
@@ -291,10 +316,14 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             // a wavefront whose 64 + 64 windows all lie beyond the tile's last window has nothing to evaluate (wave-uniform branch)
             if (base + (tid & ~63u) >= n_in) continue;
             ht_gen_stage_0_x2(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), lds + (valid[1] ? 2u * (yy[1] * PITCH0 + xx[1]) : 0u), Fv[0], Fv[1]);
+            // Both decisions first, the (rare) tie branches after them: the arithmetic of both windows stays in the basic block of
+            // its loads.  hipcc narrows the byte min / max to 16-bit operations and, for a value that crosses a block boundary, no
+            // longer knows that ds_read_u8 zero-extends: a v_and 0xff per pixel, +40 % VALU instructions in this loop.
             bool pass[2];
+            pass[0] = (Fv[0] >= HT_GEN_FMIN[0]) & valid[0];
+            pass[1] = (Fv[1] >= HT_GEN_FMIN[0]) & valid[1];
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                pass[u] = valid[u] && Fv[u] >= HT_GEN_FMIN[0];
                 if (valid[u] && (Fv[u] == HT_GEN_FTIE[0] || force_exact))  // exact tie: the sequential binary64 sum decides
                     pass[u] = !(eval_stage_lds(lds, 2u * (yy[u] * PITCH0 + xx[u]), feats + st0.first, st0.count) < st0.threshold);
             }
@@ -315,6 +344,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         __syncthreads();
         if (tid == 0) s_nout = 0;
         cur ^= QX;
+        TL_STAMP(1);
         if (n_in == 0) return;
         __syncthreads();
         s_first = 1;
@@ -346,6 +376,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 e.pad2 = 0;
                 queue[qb + i] = e;
             }
+            TL_STAMP(10);
             if (npush == n_in) return;  // the common case
             if (tid == 0) atomicAdd(&ctr->queue_inline, n_in - npush);
             qoff += npush;  // queue full: finish the remaining survivors right here
@@ -398,9 +429,10 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 }
                 if (base + (tid & ~63u) >= n_in) continue;  // no survivor on this wavefront (after the barrier: every wave hits it)
                 ht_gen_stage_1_x2(lds + (valid[0] ? Bv[0] : 0u), lds + (valid[1] ? Bv[1] : 0u), Fv[0], Fv[1]);
+                pass[0] = (Fv[0] >= HT_GEN_FMIN[1]) & valid[0];
+                pass[1] = (Fv[1] >= HT_GEN_FMIN[1]) & valid[1];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
-                    pass[u] = valid[u] && Fv[u] >= HT_GEN_FMIN[1];
                     if (valid[u] && (Fv[u] == HT_GEN_FTIE[1] || force_exact))  // exact tie: the sequential binary64 sum decides
                         pass[u] = !(eval_stage_lds(lds, Bv[u], F, st.count) < st.threshold);
                 }
@@ -477,6 +509,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         if (tid == 0) s_nout = 0;
         cur ^= QX;
         qoff = 0;
+        TL_STAMP(1 + min(s, 8));
         if (n_in == 0) return;
         // s_nout reset is ordered before its next use by the __syncthreads at the end of the next stage's loop body:
         // the next atomicAdd(&s_nout) can only come after every thread passed this point, but tid 0 might still be
@@ -1101,12 +1134,29 @@ ht_status ht_scan_plan_tiles(ht_ctx *c) {
     }
     c->tiles_per_frame = tiles;
     if (!c->h_scales.empty()) {
-        std::vector<HtBlockRef> refs;
-        for (size_t si = 0; si < c->h_scales.size(); si++)
-            for (int y = 0; y < c->h_scales[si].nty; y++)
-                for (int x = 0; x < c->h_scales[si].ntx; x++) refs.push_back(HtBlockRef{(uint16_t)si, (uint16_t)x, (uint16_t)y, 0});
-        HT_HIP(c, hipMalloc(&c->d_tile_refs, refs.size() * sizeof(HtBlockRef)));
-        HT_HIP(c, hipMemcpy(c->d_tile_refs, refs.data(), refs.size() * sizeof(HtBlockRef), hipMemcpyHostToDevice));
+        std::vector<HtTileRec> recs;
+        for (const HtScanScale &S : c->h_scales) {
+            const HtDevLevel &A = c->h_levels[S.l0], &B = c->h_levels[S.l1], &Cq = c->h_levels[S.l2];
+            if (A.stride > 0xffff || A.h > 0xffff) return ht_fail(c, HT_ERR_INVALID, "frame too large");
+            for (int y = 0; y < S.nty; y++)
+                for (int x = 0; x < S.ntx; x++) {
+                    HtTileRec r;
+                    std::memset(&r, 0, sizeof(r));
+                    const int X0 = x * S.tw2, Y0 = y * S.th2;
+                    r.off0 = A.off[0], r.off1 = B.off[0];
+                    for (int q = 0; q < 4; q++) r.off2[q] = Cq.off[q];
+                    r.sh0 = (uint32_t)A.stride | (uint32_t)A.h << 16;
+                    r.sh1 = (uint32_t)B.stride | (uint32_t)B.h << 16;
+                    r.sh2 = (uint32_t)Cq.stride | (uint32_t)Cq.h << 16;
+                    r.origin = (uint32_t)X0 | (uint32_t)Y0 << 16;
+                    r.size = (uint32_t)std::min(S.tw2, 2 * S.qw - X0) | (uint32_t)std::min(S.th2, 2 * S.qh - Y0) << 16;
+                    r.tw2_l0 = (uint32_t)S.tw2 | (uint32_t)S.l0 << 16;
+                    r.div_magic = S.div_magic;
+                    recs.push_back(r);
+                }
+        }
+        HT_HIP(c, hipMalloc(&c->d_tile_recs, recs.size() * sizeof(HtTileRec)));
+        HT_HIP(c, hipMemcpy(c->d_tile_recs, recs.data(), recs.size() * sizeof(HtTileRec), hipMemcpyHostToDevice));
         HT_HIP(c, hipMalloc(&c->d_scales, c->h_scales.size() * sizeof(HtScanScale)));
         HT_HIP(c, hipMemcpy(c->d_scales, c->h_scales.data(), c->h_scales.size() * sizeof(HtScanScale), hipMemcpyHostToDevice));
     }
@@ -1126,12 +1176,12 @@ static ht_status launch_tiles(ht_ctx *c, uint32_t flags, hipStream_t stream, uin
     const int stop_stage = c->dbg_stop_stage, force_exact = c->dbg_force_exact;
     HtProfScope ps(c, "scan_tiles", stream);
     if (gen)
-        hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, stream, c->d_arena, c->arena_stride, c->d_levels, c->d_scales,
-                           c->d_tile_refs + first, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
+        hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, stream, c->d_arena, c->arena_stride,
+                           c->d_tile_recs + first, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
                            c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
     else
-        hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, stream, c->d_arena, c->arena_stride, c->d_levels, c->d_scales,
-                           c->d_tile_refs + first, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
+        hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, stream, c->d_arena, c->arena_stride,
+                           c->d_tile_recs + first, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
                            c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
     HT_HIP(c, hipGetLastError());
     return HT_OK;

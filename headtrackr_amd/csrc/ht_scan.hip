@@ -183,6 +183,31 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     __shared__ uint32_t s_nout;
     __shared__ uint32_t s_qbase;
     __shared__ uint32_t s_F[64];  // sparse phase: per-survivor integer stage sums assembled from the 4 waves' slices
+#ifndef HT_TILE_WAVEQ
+#define HT_TILE_WAVEQ 1
+#endif
+#ifndef HT_TILE_MERGE_FROM
+#define HT_TILE_MERGE_FROM 2  // the first stage after which the wavefronts compare their survivor counts
+#endif
+#if HT_TILE_WAVEQ && HT_TILE_QIN12 && HT_TILE_INPLACE
+    // Wave-private layout of the same row tails (see "wave-private cascade" below): rows [8w, 8w + 8) = wavefront w's queue of
+    // window ids (a wavefront enumerates at most MAXWIN / 4 = 512 windows), rows 32-37 = three buffers of 64 per-survivor integer
+    // stage sums (36 dwords of tail per row: 32 used), row 38 = the wavefronts' survivor counts (two parities x 4).
+    constexpr int WQ_ROWS = MAXWIN / NT, WQ_CAP = WQ_ROWS * 64;
+    static_assert(NT != 256 || GH >= 4 * WQ_ROWS + 7, "wave-private queues do not fit the row tails");
+#define QW(w_, e_) QB(0, (w_) * WQ_CAP + (e_))
+#define SF(b_, l_) (*reinterpret_cast<uint32_t *>(&lds[P12_BASE + 160 + (4 * WQ_ROWS + 2 * (b_) + ((l_) >> 5)) * G_PITCH + (((l_)&31u) << 2)]))
+#define SCNT(p_) (reinterpret_cast<uint32_t *>(&lds[P12_BASE + 160 + (4 * WQ_ROWS + 6) * G_PITCH + (p_) * 16]))
+    constexpr bool WAVEQ = GEN && NT == 256;
+    constexpr bool LGEN = false;  // the shared-queue code below keeps the table-driven stages only (it runs the stages past the generated ones)
+#else
+    constexpr bool WAVEQ = false;
+    constexpr bool LGEN = GEN;
+#define QW(w_, e_) QB(0, 0)
+#define SF(b_, l_) s_F[l_]
+#define SCNT(p_) (&s_qbase)
+    constexpr int WQ_CAP = 0;
+#endif
 
     // XCD-aware tile order: consecutive tiles (same frame / scale, shared halos) stay on one XCD's L2.
     const uint32_t nb = gridDim.x, chunk = nb >> 3;  // gridDim.x is a multiple of 8
@@ -287,19 +312,163 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         }
     }
     if (tid == 0) s_nout = 0;
+    if (WAVEQ && tid < 192u) SF(tid >> 6, tid & 63u) = 0u;
     __syncthreads();
     TL_STAMP(0);
 
     // ---- cascade with per-stage compaction -------------------------------------------------------------------
+    // ---- wave-private cascade (built-in cascade) ----------------------------------------------------------------
+    // Shader-clock stamps (tools/gpu_tile_timeline.py) showed every stage costing a workgroup ~3 000 cycles whatever its survivor
+    // count: not arithmetic but the DEPENDENT LDS round trips of the shared-queue machinery (queue read, feature loads, queue
+    // reservation by LDS atomic, queue write, counter read — each one waits behind the ~24 wavefronts' queued LDS traffic of the
+    // CU) and 4-5 workgroup barriers.  Here a wavefront keeps the survivors of ITS windows in a queue of its own: compaction is
+    // ballot + popcount in registers, no atomics and no barriers; per stage it pays two round trips (ids, feature pixels).
+    // After stage HT_TILE_MERGE_FROM the four wavefronts publish their counts (one barrier); once <= 64 windows are left in the
+    // tile every wavefront pulls all of them into registers (lane = survivor, the same in all four wavefronts) and the
+    // stages are evaluated in four feature slices whose integer partial sums meet in LDS: one atomic add, one barrier and one
+    // read per stage, no queue.  Window sets and stage decisions are exactly those of the shared-queue code below, which still
+    // serves other cascades, the stages past the generated ones and the hand-off to k_scan_deep.
     uint32_t n_in = (uint32_t)(S.tw2 * th);  // stage 0 enumerates id = Y'*tw2 + X' (X' >= tw is masked off)
     uint32_t qoff = 0;                        // start of the live entries inside qbuf[cur]
     int cur = 0;
     bool pushed = (split >= nstages);
+    int s_first = 0;
+    const int wq_lim = min(min(split, nstages - 1), (int)HT_GEN_STAGES);  // stages [0, wq_lim) run wave-private
+    if (WAVEQ && wq_lim >= 1) {
+        const uint32_t wv = tid >> 6;
+        if (stop_stage == 0) return;
+        uint32_t wq = 0;  // survivors of this wavefront's windows (wave-uniform)
+        {
+            const HtDevStage st0 = stages[0];
+            for (uint32_t base = 0; base < n_in; base += 2 * NT) {
+                uint32_t id[2], xx[2], yy[2], Fv[2];
+                bool valid[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t pos = base + u * NT + tid;
+                    valid[u] = pos < n_in;
+                    id[u] = valid[u] ? pos : 0u;
+                    yy[u] = __umul24(id[u], S.div_magic) >> 20;  // 24-bit multiplies: v_mul_lo_u32 is quarter rate (id < 2^11, magic < 2^18)
+                    xx[u] = id[u] - __umul24(yy[u], (uint32_t)S.tw2);
+                    valid[u] = valid[u] && xx[u] < (uint32_t)tw;
+                }
+                if (base + (tid & ~63u) >= n_in) break;  // this wavefront's windows are exhausted (its ids only grow)
+                ht_gen_stage_0_x2(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), lds + (valid[1] ? 2u * (yy[1] * PITCH0 + xx[1]) : 0u), Fv[0], Fv[1]);
+                bool pass[2];
+                pass[0] = (Fv[0] >= HT_GEN_FMIN[0]) & valid[0];
+                pass[1] = (Fv[1] >= HT_GEN_FMIN[0]) & valid[1];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (valid[u] && (Fv[u] == HT_GEN_FTIE[0] || force_exact))  // exact tie: the sequential binary64 sum decides
+                        pass[u] = !(eval_stage_lds(lds, 2u * (yy[u] * PITCH0 + xx[u]), feats + st0.first, st0.count) < st0.threshold);
+                }
+                const unsigned long long m0 = __ballot(pass[0]), m1 = __ballot(pass[1]);
+                const uint32_t c0 = __popcll(m0), c1 = __popcll(m1);
+                if (pass[0]) QW(wv, wq + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) = (uint16_t)id[0];
+                if (pass[1]) QW(wv, wq + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) = (uint16_t)id[1];
+                wq += c0 + c1;
+            }
+            if (tid == 0 && my_stats) atomicAdd(&my_stats[0], (unsigned long long)(uint32_t)(tw * th));
+        }
+        // -- stages 1.. on the wavefront's own queue, until the tile is down to one wavefront of windows
+        int s = 1;
+        uint32_t total = 0;
+        uint4 cn = make_uint4(0u, 0u, 0u, 0u);
+        bool gather = false;
+        for (;; s++) {
+            if (s > HT_TILE_MERGE_FROM || s == wq_lim) {
+                if (lane == 0) SCNT(s & 1)[wv] = wq;
+                __syncthreads();
+                cn = *reinterpret_cast<const uint4 *>(SCNT(s & 1));
+                total = cn.x + cn.y + cn.z + cn.w;
+                TL_STAMP(s);
+                if (total == 0) return;
+                if (total <= 64u && s < wq_lim) {
+                    gather = true;
+                    break;
+                }
+                if (s == wq_lim) break;
+            } else {
+                TL_STAMP(s);
+            }
+            if (s == stop_stage) return;
+            if (lane == 0 && my_stats && wq) atomicAdd(&my_stats[s], (unsigned long long)wq);
+            uint32_t out = 0;
+            for (uint32_t b = 0; b < wq; b += 64) {
+                const bool valid = b + lane < wq;
+                const uint32_t wid = valid ? (uint32_t)QW(wv, b + lane) : 0u;
+                const uint32_t yy = __umul24(wid, S.div_magic) >> 20, xx = wid - __umul24(yy, (uint32_t)S.tw2);
+                const uint32_t Bw = 2u * (yy * PITCH0 + xx);
+                const uint32_t Fv = ht_gen_stage(s, lds + (valid ? Bw : 0u));
+                bool pass = (Fv >= HT_GEN_FMIN[s]) & valid;
+                if (valid && (Fv == HT_GEN_FTIE[s] || force_exact)) {  // exact tie with the threshold: the sequential binary64 sum decides
+                    const HtDevStage st = stages[s];
+                    pass = !(eval_stage_lds(lds, Bw, feats + st.first, st.count) < st.threshold);
+                }
+                const unsigned long long m = __ballot(pass);
+                // in place: position out + (survivors before this lane) <= b + lane, an entry this chunk has already read
+                if (pass) QW(wv, out + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) = (uint16_t)wid;
+                out += (uint32_t)__popcll(m);
+            }
+            wq = out;
+        }
+        if (gather) {
+            // -- <= 64 windows left in the tile: lane = survivor in every wavefront, stages in four feature slices
+            const uint32_t o1 = cn.x, o2 = o1 + cn.y, o3 = o2 + cn.z;
+            const uint32_t j = (lane >= o1 ? 1u : 0u) + (lane >= o2 ? 1u : 0u) + (lane >= o3 ? 1u : 0u);
+            const uint32_t e = lane - (j == 0 ? 0u : (j == 1 ? o1 : (j == 2 ? o2 : o3)));
+            bool alive = lane < total;
+            const uint32_t wid = alive ? (uint32_t)QW(j, e) : 0u;
+            const uint32_t yy = __umul24(wid, S.div_magic) >> 20, xx = wid - __umul24(yy, (uint32_t)S.tw2);
+            const uint32_t Bw = 2u * (yy * PITCH0 + xx);
+            for (; s < wq_lim; s++) {
+                if (s == stop_stage) return;
+                const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+                if (tid == 0 && my_stats) atomicAdd(&my_stats[s], (unsigned long long)n_alive);
+                const uint32_t bi = (uint32_t)s % 3u;
+                const uint32_t part = ht_gen_stage_slice(s, (int)wv, lds + (alive ? Bw : 0u));
+                if (alive && part) atomicAdd(&SF(bi, lane), part);
+                __syncthreads();
+                const uint32_t Fv = SF(bi, lane);
+                // the buffer of stage s-1 (= s+2 mod 3): every wavefront read it before this stage's barrier, stage s+2 adds to it after the next one
+                if (wv == 0) SF((uint32_t)(s + 2) % 3u, lane) = 0u;
+                bool pass = (Fv >= HT_GEN_FMIN[s]) & alive;
+                if (alive && (Fv == HT_GEN_FTIE[s] || force_exact)) {
+                    const HtDevStage st = stages[s];
+                    pass = !(eval_stage_lds(lds, Bw, feats + st.first, st.count) < st.threshold);
+                }
+                alive = pass;
+                TL_STAMP(1 + s);
+                if (!__ballot(alive)) return;  // the same decision in all four wavefronts
+            }
+            // the generated stages are done: the survivors go on through the shared queue (hand-off to the deep kernel, or the table-driven stages)
+            const unsigned long long m = __ballot(alive);
+            if (wv == 0 && alive) QB(0, __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) = (uint16_t)wid;
+            n_in = (uint32_t)__popcll(m);
+            __syncthreads();
+        } else {
+            // more than one wavefront of windows survived every generated stage (dense face texture): the four queues become the
+            // shared one, wavefront by wavefront (a wavefront moves its entries down, never past the next wavefront's first entry)
+            const uint32_t off = (wv == 0 ? 0u : (wv == 1 ? cn.x : (wv == 2 ? cn.x + cn.y : cn.x + cn.y + cn.z)));
+            for (uint32_t w = 1; w < 4; w++) {
+                __syncthreads();
+                if (wv == w) {
+                    for (uint32_t b = 0; b < wq; b += 64) {
+                        const bool valid = b + lane < wq;
+                        const uint32_t wid = valid ? (uint32_t)QW(w, b + lane) : 0u;
+                        if (valid) QB(0, off + b + lane) = (uint16_t)wid;
+                    }
+                }
+            }
+            __syncthreads();
+            n_in = total;
+        }
+        s_first = s;
+    } else
     // ---- stage 0, generated code, two windows per thread per iteration: every window of the tile runs it (74 % of
     // them end here), so it gets its own loop: the two independent evaluations give the scheduler twice the LDS reads
     // to keep in flight per wait.
-    int s_first = 0;
-    if (GEN && stop_stage != 0 && split > 0 && nstages > 1) {
+    if (LGEN && stop_stage != 0 && split > 0 && nstages > 1) {
         const HtDevStage st0 = stages[0];
         for (uint32_t base = 0; base < n_in; base += 2 * NT) {
             uint32_t id[2], xx[2], yy[2], Fv[2];
@@ -384,7 +553,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         }
         const HtTileFeature *F = feats + st.first;
         const bool last = (s == nstages - 1);
-        if (GEN && NT == 256 && s < HT_GEN_STAGES && n_in <= 64u) {
+        if (LGEN && NT == 256 && s < HT_GEN_STAGES && n_in <= 64u) {
             // sparse phase: at most one wavefront of survivors left.  Instead of one wave walking the whole stage while
             // three idle at the barrier, every wave takes the features k % 4 == wave for ALL survivors and the partial
             // integer sums meet in LDS (exact: integer addition is order-free) — the stage takes a quarter of the time,
@@ -409,7 +578,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 if (pass) QB(cur ^ QX, pre) = (uint16_t)id;
                 if (lane == 0) s_nout = (uint32_t)__popcll(m);
             }
-        } else if (GEN && s == 1 && n_in > (uint32_t)NT) {
+        } else if (LGEN && s == 1 && n_in > (uint32_t)NT) {
             // stage 1 typically still has ~1.7 survivors per thread: two windows per thread per pass like stage 0 (twice
             // the LDS reads in flight per wait, half the passes, barriers and queue reservations)
             for (uint32_t base = 0; base < n_in; base += 2 * NT) {
@@ -463,7 +632,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             const uint32_t B = 2u * (yy * PITCH0 + xx);
             double sum = 0.0;
             bool pass;
-            if (GEN && s < HT_GEN_STAGES) {
+            if (LGEN && s < HT_GEN_STAGES) {
                 // generated straight-line stage: exact integer decision (see tools/gen_cascade_code.py)
                 const uint32_t Fv = ht_gen_stage(s, lds + (valid ? B : 0u));
                 pass = valid && Fv >= HT_GEN_FMIN[s];

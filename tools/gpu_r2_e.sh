@@ -22,7 +22,7 @@ run() {
 }
 cp $LIB /tmp/base.so
 run new
-for n in old asm asm7 c7; do
+for n in ${AB_ALTS:-old mf1 mf3}; do
   [ -f alt/$n.so ] || continue
   cp alt/$n.so $LIB
   run $n

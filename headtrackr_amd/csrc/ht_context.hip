@@ -470,6 +470,13 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
                     // bit 0: exact 2:1 in both directions (2x2 box mean in integers, see rs_pixels4_lds); HT_DEBUG_RS_NOFAST=1 keeps
                     // every pixel on the declared binary64 sequence (A/B and cross-check)
                     t.pad = getenv("HT_DEBUG_RS_NOFAST") ? 2 : (uint16_t)((j.dw > 0 && j.sw == 2 * j.dw && j.sh == 2 * j.dh) ? 1 : 0);
+                    const int X0 = 64 * x, Y0 = 16 * pass0, ncols = std::min(64, j.dw - X0), nrows = std::min(16 * np, j.dh - Y0);
+                    if (ncols > 0 && nrows > 0) {  // the source extent k_resample stages into LDS (same expressions as in the kernel)
+                        t.ex_xa = ht_host_tap(X0, j.rx, j.sw, j.sx).a & ~15;
+                        t.ex_ya = ht_host_tap(Y0, j.ry, j.sh, j.sy).a;
+                        t.ex_sw16 = (ht_host_tap(X0 + ncols - 1, j.rx, j.sw, j.sx).b - t.ex_xa) / 16 + 1;
+                        t.ex_sh = ht_host_tap(Y0 + nrows - 1, j.ry, j.sh, j.sy).b - t.ex_ya + 1;
+                    }
                     tiles.push_back(t);
                 }
                 pass0 += np;

@@ -124,6 +124,11 @@ struct HtResampleJob {
     uint16_t bx, pass0;      // tile record only: tile column (64 px), first 16-row pass
     uint16_t np, pad;        // tile record only: number of 16-row passes (<= HT_RS_MAX_PASSES)
     double rx, ry;           // sw/dw, sh/dh computed on the host (binary64 division)
+    // tile record only: the source rectangle the tile's taps touch, from the host (ht_host_tap: the same binary64 operations as
+    // rs_tap).  ex_sw16 == 0: not filled in, the kernel derives it (four rs_tap evaluations, ~1 400 cycles at the top of every
+    // workgroup before its first load can be issued)
+    int32_t ex_xa, ex_ya;    // first source column (rounded down to 16) / row
+    int32_t ex_sw16, ex_sh;  // 16-byte chunks per source row, source rows
 };
 
 // One scan scale (ccv.js:154-160) and its tiling.

@@ -12,6 +12,10 @@
 // 191-192), so each plane is stored once as 1 byte/pixel (row stride = width rounded up to 4, plane base 256-B
 // aligned) inside a per-frame arena; frames are arena_stride bytes apart.  All kernels take the frame index from
 // blockIdx.y so a whole batch is one launch per dependency generation.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
 #include "ht_internal.h"
 
 namespace {
@@ -259,7 +263,22 @@ __device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int
 #ifndef HT_RS_EXPERIMENT
 #define HT_RS_EXPERIMENT 0  // timing experiments only (results are wrong): 1 = no pixel arithmetic, 2 = no source loads
 #endif
-#ifdef HT_RS_TIMELINE  // tools/micro/resample_timeline.hip: shader-clock stamps of the phases of every workgroup
+#if defined(HT_RS_PHASES)  // tools/gpu_rs_phases.py: shader-clock stamps of every phase of every frame iteration, plain stores into per-workgroup slots
+__device__ unsigned long long g_rs_tl[16384][8][8];  // [slot][frame iteration & 7][stamp]
+#define HT_RS_TIMELINE 1
+#define RS_SUB(i)                                                                       \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (threadIdx.x == 0) g_rs_tl[rs_slot][7][i] = __builtin_readcyclecounter();    \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#define RS_STAMP(i)                                                                     \
+    do {                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+        if (threadIdx.x == 0) g_rs_tl[rs_slot][rs_iter & 7u][i] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                              \
+    } while (0)
+#elif defined(HT_RS_TIMELINE)  // tools/micro/resample_timeline.hip: shader-clock stamps of the phases of every workgroup
 __device__ unsigned long long g_rs_timeline[1 << 16][8];
 #define RS_STAMP(i)                                                                     \
     do {                                                                                \
@@ -269,6 +288,9 @@ __device__ unsigned long long g_rs_timeline[1 << 16][8];
     } while (0)
 #else
 #define RS_STAMP(i)
+#endif
+#ifndef RS_SUB
+#define RS_SUB(i)
 #endif
 // One workgroup = one tile record x one group of K consecutive frames.  A tile is 64 columns x (16 * np) rows of one
 // drawImage call, np <= RPT passes chosen per tile by the host (ht_context.hip) so that (a) a level's rows are split
@@ -290,6 +312,10 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
     __shared__ RsTap s_col[RS_TW], s_row[TH];
     uint32_t gidx, blk;
     if (!xcd_item(blocks_per_frame, ngroups, &gidx, &blk)) return;
+#ifdef HT_RS_PHASES
+    const uint32_t rs_slot = (blockIdx.x ^ (blocks_per_frame * 2654435761u)) & 16383u;  // different launches mostly land in different slots
+    uint32_t rs_iter = 0;
+#endif
     RS_STAMP(0);
     const HtResampleJob &J = tiles[blk];
     const uint32_t f0 = gidx * group_frames, f1 = min(f0 + group_frames, nframes);
@@ -301,15 +327,21 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
     const int x0 = X0 + (tid & 15) * 4, yt = Y0 + (tid >> 4);                  // this thread: rows yt, yt+16, ...
     const int npx = min(4, J.dw - x0);
     const bool drawn = ncols > 0 && nrows > 0;
+    RS_SUB(0);
     int xa = 0, ya = 0, sw16 = 1, sh = 1;
     bool in_lds = false;
     if (drawn) {
-        xa = rs_tap(X0, J.rx, J.sw, J.sx).a & ~15;
-        ya = rs_tap(Y0, J.ry, J.sh, J.sy).a;
-        sw16 = (rs_tap(X0 + ncols - 1, J.rx, J.sw, J.sx).b - xa) / 16 + 1;  // 16-byte chunks per source row
-        sh = rs_tap(Y0 + nrows - 1, J.ry, J.sh, J.sy).b - ya + 1;           // source rows
+        if (J.ex_sw16 > 0) {  // from the host (ht_context.hip)
+            xa = J.ex_xa, ya = J.ex_ya, sw16 = J.ex_sw16, sh = J.ex_sh;
+        } else {
+            xa = rs_tap(X0, J.rx, J.sw, J.sx).a & ~15;
+            ya = rs_tap(Y0, J.ry, J.sh, J.sy).a;
+            sw16 = (rs_tap(X0 + ncols - 1, J.rx, J.sw, J.sx).b - xa) / 16 + 1;  // 16-byte chunks per source row
+            sh = rs_tap(Y0 + nrows - 1, J.ry, J.sh, J.sy).b - ya + 1;           // source rows
+        }
         in_lds = (sw16 * 16 <= RS_SP) && (sh <= SR);
     }
+    RS_SUB(1);
     if (in_lds) {
         // source rows as 16-byte chunks.  10 threads share a row (= the 160-byte LDS pitch), 25 rows per pass.  Plane
         // strides are only 4-byte multiples, so the chunks are dword- not 16-byte-aligned in HBM and may run past the
@@ -332,9 +364,12 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         v2 = *reinterpret_cast<const uint4 *>((base) + soff2);          \
         v3 = *reinterpret_cast<const uint4 *>((base) + soff3);          \
     } while (0)
+        RS_SUB(2);
         RS_LOAD_TILE(frame);
+        RS_SUB(3);
         if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
         if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
+        RS_SUB(4);
         __syncthreads();
         RS_STAMP(1);
         int ia[4], ib[4];
@@ -387,6 +422,9 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
             }
             if (f + 1 < f1) __syncthreads();  // every wave is done reading this frame's tile
             RS_STAMP(6);
+#ifdef HT_RS_PHASES
+            rs_iter++;
+#endif
         }
         return;
     }
@@ -719,3 +757,38 @@ ht_status ht_launch_whitebalance(ht_ctx *c, double *d_out, bool zero) {
     HT_HIP(c, hipGetLastError());
     return HT_OK;
 }
+
+#ifdef HT_RS_PHASES
+// sums per phase over all recorded frame iterations: out16[i] = cycles between stamp i-1 and stamp i (i = 3..6; 2 = from the previous
+// iteration's stamp 6), out16[8 + i] = samples
+extern "C" int ht_debug_rs_phases(unsigned long long *out16, int reset) {
+    static unsigned long long h[16384][8][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rs_tl), sizeof(h)) != hipSuccess) return 1;
+    for (int j = 0; j < 16; j++) out16[j] = 0;
+    for (int sl = 0; sl < 16384; sl++)
+        for (int it = 0; it < 8; it++) {
+            const unsigned long long *t = h[sl][it];
+            if (!t[2] || !t[6] || t[6] < t[2] || t[6] - t[2] > (1ull << 24)) continue;  // empty or torn slot
+            for (int i = 3; i <= 6; i++)
+                if (t[i] >= t[i - 1]) out16[i] += t[i] - t[i - 1], out16[8 + i]++;
+            if (it == 0 && h[sl][0][1] && t[2] >= h[sl][0][1]) out16[2] += t[2] - h[sl][0][1], out16[8 + 2]++;
+            if (it == 0 && h[sl][0][0] && h[sl][0][1] >= h[sl][0][0]) out16[1] += h[sl][0][1] - h[sl][0][0], out16[8 + 1]++;
+        }
+    if (const char *e = std::getenv("HT_RS_SUBSTAMPS")) {  // setup sub-phases: entry -> record/extent inputs -> extents -> addresses -> loads issued -> taps -> barrier
+        (void)e;
+        unsigned long long sum[6] = {}, n = 0;
+        for (int sl = 0; sl < 16384; sl++) {
+            const unsigned long long *u = h[sl][7], t0 = h[sl][0][0], t1 = h[sl][0][1];
+            if (!t0 || !t1 || !u[0] || !u[4] || t1 < t0 || t1 - t0 > (1ull << 24) || u[0] < t0 || u[4] > t1) continue;
+            sum[0] += u[0] - t0, sum[1] += u[1] - u[0], sum[2] += u[2] - u[1], sum[3] += u[3] - u[2], sum[4] += u[4] - u[3], sum[5] += t1 - u[4], n++;
+        }
+        if (n) std::printf("  setup sub-phases (%llu samples): record %.0f, extents %.0f, addresses %.0f, load issue %.0f, tap tables %.0f, barrier %.0f cycles\n", n,
+                           (double)sum[0] / n, (double)sum[1] / n, (double)sum[2] / n, (double)sum[3] / n, (double)sum[4] / n, (double)sum[5] / n);
+    }
+    if (reset) {
+        std::memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_tl), h, sizeof(h)) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#endif

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""tools/gpu_rs_phases.py [c2|c4] — where a k_resample workgroup spends its life, from a -DHT_RS_PHASES build (bash tools/build_alt.sh
+rsph HT_RS_PHASES=1; copy alt/rsph.so over the library).  Phases: 1 record + taps + first loads issued + barrier (once per workgroup);
+per frame of the group: 2 loop top, 3 source tile regs -> LDS (waits for the prefetched loads), 4 barrier, 5 next frame's loads issued +
+pixels, 6 stores + barrier."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from headtrackr_amd import synth  # noqa: E402
+from headtrackr_amd.api import Context  # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
+W, H, n, uniq = (320, 240, 256, 256) if wl == "c2" else (1280, 720, 128, 12)
+base = synth.mixed_batch(uniq, W, H, seed0=1234)
+frames = base[np.arange(n) % uniq]
+c = Context()
+lib = c._lib
+lib.ht_debug_rs_phases.argtypes = [C.c_void_p, C.c_int]
+raw = np.zeros(16, dtype=np.uint64)
+c.detect_raw(frames, cap=1 << 18)
+lib.ht_debug_rs_phases(raw.ctypes.data, 1)
+for rep in range(3):
+    c.detect_raw(frames, cap=1 << 18)
+lib.ht_debug_rs_phases(raw.ctypes.data, 1)
+cyc, cnt = raw[:8].astype(np.float64), raw[8:].astype(np.float64)
+tot = cyc.sum()
+names = {1: "setup + first loads + barrier", 2: "stamp 1 -> first loop top", 3: "regs -> LDS (load wait)", 4: "barrier", 5: "prefetch issue + pixels", 6: "stores + barrier"}
+print(f"{wl}: {int(cnt[3])} frame iterations sampled, mean iteration {sum(cyc[3:7]) / max(cnt[3], 1):.0f} cycles")
+for p in range(1, 7):
+    if cnt[p] > 0:
+        print(f"  {names[p]:30s} visits {int(cnt[p]):8d}  mean {cyc[p] / cnt[p]:8.0f} cycles  {100 * cyc[p] / tot:5.1f} % of all workgroup-cycles")

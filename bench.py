@@ -55,7 +55,8 @@ def parse():
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic frames generated (tiled to --frames)")
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
-    ap.add_argument("--pipeline", type=int, default=3, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn")
+    ap.add_argument("--pipeline", type=int, default=0, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn; "
+                    "0 = auto: 3 while one batch (frames + pyramid) fits the 256 MB Infinity Cache, else 2 (measured: 320x240 x 256 best at 3, 1280x720 x 128 at 2)")
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steady-state work before the warm-up steps (0 for profiler runs)")
     ap.add_argument("--no-sub", action="store_true", help="only the primary workload (no c4 / c3 sub-records)")
     a = ap.parse_args()
@@ -210,7 +211,8 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     idx = torch.arange(nf, device="cuda") % uniq
     dev = dev_uniq[idx].contiguous() if nf != uniq else dev_uniq  # resident in HBM before the timed region
     del dev_uniq
-    depth = max(1, a.pipeline)
+    batch_bytes = nf * (W * H * 4 + int(1.45 * W * H))  # RGBA frames + ~1.43 gray bytes of pyramid planes per pixel (P / (W H))
+    depth = a.pipeline if a.pipeline > 0 else (3 if batch_bytes <= (256 << 20) else 2)
     ctxs = []
     for _ in range(depth):
         cx = Context(device=local)
@@ -403,7 +405,9 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
     win_px_per_call = float(px.sum()) / max(float(calls.sum()), 1.0)
     b_track = 4 * W * H + 4 * win_px_per_call  # one full-frame histogram pass + the window passes, per stream and call
     # >= 192 streams: ONE kernel per call (k_cs_track_fused: histogram + LUT + mean-shift); fewer: k_cs_hist + k_cs_meanshift
-    per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items() if k in ("cs_hist", "cs_meanshift", "cs_track")}
+    # (with >= 192 streams ht_camshift_track_sequence puts up to 64 calls of every stream into one launch: times are per CALL below)
+    launches = {k: v["launches"] for k, v in kt.items() if k in ("cs_hist", "cs_meanshift", "cs_track")}
+    per_launch = {k: v["ms"] / CALLS for k, v in kt.items() if k in launches}
     dom = max(per_launch, key=per_launch.get)
     call_ms = sum(per_launch.values())
     achieved = b_track * nf / (per_launch[dom] * 1e-3) / 1e9
@@ -415,7 +419,7 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
                    "host_calls_per_step": "ht_detect_enqueue/collect + ht_best_faces + ht_camshift_init_batch + ONE ht_camshift_track_sequence (60 calls)"},
         "roofline": dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
                          algorithmic_bytes_per_stream_call=round(b_track, 1), window_pixels_per_call=round(win_px_per_call, 1), streams_per_launch=nf,
-                         avg_launch_ms=round(per_launch[dom], 5)),
+                         calls_per_launch=round(CALLS / max(launches[dom], 1), 1), avg_launch_ms=round(per_launch[dom] * CALLS / max(launches[dom], 1), 5)),
         "kernel_ms_per_track_call": {k: round(v, 5) for k, v in per_launch.items()},
         "kernel_rooflines": {k: dict(own_bytes_per_call=round(own[k]), gbs=round(own[k] / (per_launch[k] * 1e-3) / 1e9, 1),
                                      frac=round(own[k] / (per_launch[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) for k in per_launch},

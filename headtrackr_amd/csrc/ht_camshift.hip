@@ -454,9 +454,19 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
 constexpr int FUSED_NT = 1024;
 constexpr int CS_REGION_CAP = 40960;  // pixels of the cached search region: 80 KB of LDS next to the 32 KB LUT and the 16 KB histogram
 
-__global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H, uint32_t npix,
+// Up to CS_SEQ_MAX successive track() calls of every stream in ONE launch (ht_camshift_track_sequence): the frame batches of the calls
+// travel as kernel arguments, a workgroup walks its stream's calls in order.  The calls of a stream depend on each other through its
+// search window, the streams do not: with one launch per call every call waited for its slowest stream (and paid a launch); now a
+// workgroup that converges quickly on one frame is already working on the next one.
+constexpr int CS_SEQ_MAX = 64;
+struct CsFrameList {
+    const uint8_t *p[CS_SEQ_MAX];
+};
+// SEQ = false: exactly one call, no loop (the loop costs the 128-VGPR kernel a few dozen spilled loop invariants and a scratch allocation)
+template <bool SEQ>
+__global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFrameList flist, int ncalls_arg, size_t frame_stride, int W, int H, uint32_t npix,
                                                             HtCsState *__restrict__ states, int first, int calc_angles, int max_it, int region_cap,
-                                                            ht_cs_trackobj *__restrict__ out, uint32_t *__restrict__ dbg_hist) {
+                                                            ht_cs_trackobj *__restrict__ out, uint32_t out_call_stride, uint32_t *__restrict__ dbg_hist) {
     extern __shared__ __attribute__((aligned(16))) uint8_t cs_dyn[];  // [region_cap] u16 bins of the cached search region
     __shared__ double lut[4096];
     __shared__ uint32_t h[4096];
@@ -464,7 +474,10 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const uint8_t *__re
     __shared__ int s_sw[4];
     const int s = blockIdx.x;
     HtCsState &st = states[first + s];
-    const uint8_t *frame = frames + (size_t)s * frame_stride;
+    const int ncalls = SEQ ? ncalls_arg : 1;
+    for (int call = 0; call < ncalls; call++) {
+    if (call) __syncthreads();  // thread 0 stored the new search window; every wavefront is done with h / lut / the cached region
+    const uint8_t *frame = flist.p[call] + (size_t)s * frame_stride;
 #ifdef HT_CS_TIMELINE
     __shared__ unsigned long long s_stamps[32];
     if (threadIdx.x < 32) s_stamps[threadIdx.x] = 0;
@@ -569,13 +582,14 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const uint8_t *__re
     __syncthreads();  // LUT and region complete
     CS_STAMP(stamps, 3);
     const uint32_t *img = reinterpret_cast<const uint32_t *>(frame);
-    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, stamps, true, [&](bool second, int x, int y, int w, int h) {
+    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + (size_t)call * out_call_stride + s : nullptr, stamps, true, [&](bool second, int x, int y, int w, int h) {
         return second ? window_moments_any<true, FUSED_NT / 64>(img, W, lut, R, x, y, w, h, red) : window_moments_any<false, FUSED_NT / 64>(img, W, lut, R, x, y, w, h, red);
     });
 #ifdef HT_CS_TIMELINE
     if (threadIdx.x == 0 && dbg_hist)
         for (int i = 0; i < 30; i++) reinterpret_cast<unsigned long long *>(dbg_hist + (size_t)s * 4096 + 4032)[i] = s_stamps[i];
 #endif
+    }  // next call of this stream
 }
 
 // ---- few large streams: a CLUSTER of workgroups per stream ---------------------------------------------------------------
@@ -769,7 +783,7 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
                               ht_cs_trackobj *d_out) {
     const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
     if (!c->cs_attr_set) {  // the cached search region needs more than the default 64 KB of LDS per workgroup (per context = per device)
-        HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
+        HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
         HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_meanshift), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
         c->cs_attr_set = true;
     }
@@ -777,8 +791,10 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
     // (a handful of large feeds): chunk histograms from every CU, then one mean-shift workgroup per stream
     if (n >= c->cs_fused_min_streams) {
         HtProfScope ps(c, "cs_track");
-        hipLaunchKernelGGL(k_cs_track_fused, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, frames, frame_stride, c->W, c->H, npix, c->d_cs, first,
-                           calc_angles, c->dbg_cs_iters, c->cs_region_cap, d_out, c->cs_keep_hist ? c->d_cs_hist : nullptr);
+        CsFrameList fl;
+        fl.p[0] = frames;
+        hipLaunchKernelGGL(k_cs_track_fused<false>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, fl, 1, frame_stride, c->W, c->H, npix, c->d_cs, first,
+                           calc_angles, c->dbg_cs_iters, c->cs_region_cap, d_out, 0u, c->cs_keep_hist ? c->d_cs_hist : nullptr);
         HT_HIP(c, hipGetLastError());
         c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;
         return HT_OK;
@@ -849,10 +865,30 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
     }
     // the calls of one stream are sequentially dependent (search window, camshift.js:257-258), the streams are not: 2 launches
     // per call on the context's stream, no host round trip in between
-    for (int k = 0; k < ncalls; k++) {
-        ht_cs_trackobj *d_out = c->d_cs_seq_out + (out_all ? (size_t)k * n : 0);
-        ht_status st = launch_track(c, static_cast<const uint8_t *>(dev_frames[k]), frame_stride, first, n, calc_angles, d_out);
-        if (st != HT_OK) return st;
+    if (n >= c->cs_fused_min_streams && c->cs_seq_fused) {
+        // one launch per CS_SEQ_MAX calls: every workgroup walks its stream's calls on its own (see k_cs_track_fused)
+        if (!c->cs_seq_attr_set) {
+            HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
+            c->cs_seq_attr_set = true;
+        }
+        const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
+        for (int k0 = 0; k0 < ncalls; k0 += CS_SEQ_MAX) {
+            const int kc = std::min(CS_SEQ_MAX, ncalls - k0);
+            CsFrameList fl;
+            for (int k = 0; k < kc; k++) fl.p[k] = static_cast<const uint8_t *>(dev_frames[k0 + k]);
+            HtProfScope ps(c, "cs_track");
+            hipLaunchKernelGGL(k_cs_track_fused<true>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, fl, kc, frame_stride, c->W, c->H, npix, c->d_cs, first,
+                               calc_angles, c->dbg_cs_iters, c->cs_region_cap, c->d_cs_seq_out + (out_all ? (size_t)k0 * n : 0), out_all ? (uint32_t)n : 0u,
+                               c->cs_keep_hist ? c->d_cs_hist : nullptr);
+            HT_HIP(c, hipGetLastError());
+        }
+        c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;
+    } else {
+        for (int k = 0; k < ncalls; k++) {
+            ht_cs_trackobj *d_out = c->d_cs_seq_out + (out_all ? (size_t)k * n : 0);
+            ht_status st = launch_track(c, static_cast<const uint8_t *>(dev_frames[k]), frame_stride, first, n, calc_angles, d_out);
+            if (st != HT_OK) return st;
+        }
     }
     if (out) {
         HT_HIP(c, hipMemcpyAsync(out, c->d_cs_seq_out, need * sizeof(ht_cs_trackobj), hipMemcpyDeviceToHost, c->stream));

@@ -249,6 +249,7 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     if (const char *e = getenv("HT_DEBUG_DEEP_GRID")) c->deep_grid = std::max(1, atoi(e));
     if (const char *e = getenv("HT_DEBUG_CS_FUSED_MIN")) c->cs_fused_min_streams = std::max(1, atoi(e));
     if (getenv("HT_DEBUG_CS_KEEP_HIST")) c->cs_keep_hist = true;
+    if (const char *e = getenv("HT_DEBUG_CS_SEQ_FUSED")) c->cs_seq_fused = atoi(e) != 0;
     if (const char *e = getenv("HT_DEBUG_CS_CLUSTER")) c->cs_cluster = atoi(e) != 0;
     if (const char *e = getenv("HT_DEBUG_CS_CLUSTER_MINPX")) c->cs_cluster_min_px = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HT_DEBUG_CS_REGION")) c->cs_region_cap = std::min(40960, std::max(0, atoi(e)));

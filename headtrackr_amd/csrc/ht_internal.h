@@ -308,6 +308,8 @@ struct ht_ctx {
     ht_cs_trackobj *d_cs_seq_out = nullptr;  // ht_camshift_track_sequence: [calls][streams] results, one D2H at the end
     size_t cs_seq_cap = 0;
     int cs_fused_min_streams = 192;  // >= this many streams per call: k_cs_track_fused (HT_DEBUG_CS_FUSED_MIN)
+    bool cs_seq_attr_set = false;
+    bool cs_seq_fused = true;      // HT_DEBUG_CS_SEQ_FUSED=0: ht_camshift_track_sequence launches one kernel per call (A/B)
     int dbg_cs_iters = 10;            // HT_DEBUG_CS_ITERS: mean-shift iterations at most (camshift.js:284 has 10; anything else = wrong results)
     bool cs_keep_hist = false;
     bool cs_attr_set = false;         // > 64 KB dynamic LDS enabled for the camshift kernels on this context's device

@@ -357,15 +357,25 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         const uint32_t soff0 = soff + (uint32_t)(min(r0, sh - 1) * J.src_stride), soff1 = soff + (uint32_t)(min(r0 + 25, sh - 1) * J.src_stride);
         const uint32_t soff2 = soff + (uint32_t)(min(r0 + 50, sh - 1) * J.src_stride), soff3 = soff + (uint32_t)(min(r0 + 75, sh - 1) * J.src_stride);
         uint4 v0, v1, v2, v3;  // named scalars: an array assigned under `if (f + 1 < f1)` is demoted to scratch
-#define RS_LOAD_TILE(base)                                              \
+#ifndef HT_RS_PF2
+#define HT_RS_PF2 0  // 1: the source tiles of the next TWO frames are in flight (a second set of 16 staging registers)
+#endif
+#if HT_RS_PF2
+        uint4 w0, w1, w2, w3;
+#endif
+#define RS_LOAD_TILE_INTO(base, r0_, r1_, r2_, r3_)                     \
     do {                                                                \
-        v0 = *reinterpret_cast<const uint4 *>((base) + soff0);          \
-        v1 = *reinterpret_cast<const uint4 *>((base) + soff1);          \
-        v2 = *reinterpret_cast<const uint4 *>((base) + soff2);          \
-        v3 = *reinterpret_cast<const uint4 *>((base) + soff3);          \
+        r0_ = *reinterpret_cast<const uint4 *>((base) + soff0);         \
+        r1_ = *reinterpret_cast<const uint4 *>((base) + soff1);         \
+        r2_ = *reinterpret_cast<const uint4 *>((base) + soff2);         \
+        r3_ = *reinterpret_cast<const uint4 *>((base) + soff3);         \
     } while (0)
+#define RS_LOAD_TILE(base) RS_LOAD_TILE_INTO(base, v0, v1, v2, v3)
         RS_SUB(2);
         RS_LOAD_TILE(frame);
+#if HT_RS_PF2
+        if (f0 + 1 < f1) RS_LOAD_TILE_INTO(frame + arena_stride, w0, w1, w2, w3);
+#endif
         RS_SUB(3);
         if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
         if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
@@ -385,18 +395,19 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         const uint32_t mode = J.pad;  // bit 0: 2x2 box mean (both ratios exactly 2), bit 1: binary64 everywhere (set by the host)
         const int dh = J.dh, ch = J.ch, dst_stride = J.dst_stride;  // locals: not re-read from the record after each store
         const uint32_t doff = J.dst_off + (uint32_t)(yt * dst_stride + x0);
-        for (uint32_t f = f0; f < f1; f++, frame += arena_stride) {
+        // one frame: staged registers -> LDS, barrier, refill the registers with a later frame's tile, pixels, stores
+        auto step = [&](uint4 &r0_, uint4 &r1_, uint4 &r2_, uint4 &r3_, uint32_t f, uint32_t ahead) {
             RS_STAMP(2);
             uint8_t *sdst = &s_src[r0 * RS_SP + 16 * c16];
-            if (lane_on && r0 < sh) *reinterpret_cast<uint4 *>(sdst) = v0;
-            if (lane_on && r0 + 25 < sh) *reinterpret_cast<uint4 *>(sdst + 25 * RS_SP) = v1;
-            if (lane_on && r0 + 50 < sh) *reinterpret_cast<uint4 *>(sdst + 50 * RS_SP) = v2;
-            if (lane_on && r0 + 75 < sh) *reinterpret_cast<uint4 *>(sdst + 75 * RS_SP) = v3;
+            if (lane_on && r0 < sh) *reinterpret_cast<uint4 *>(sdst) = r0_;
+            if (lane_on && r0 + 25 < sh) *reinterpret_cast<uint4 *>(sdst + 25 * RS_SP) = r1_;
+            if (lane_on && r0 + 50 < sh) *reinterpret_cast<uint4 *>(sdst + 50 * RS_SP) = r2_;
+            if (lane_on && r0 + 75 < sh) *reinterpret_cast<uint4 *>(sdst + 75 * RS_SP) = r3_;
             RS_STAMP(3);
             __syncthreads();
             RS_STAMP(4);
-            if (f + 1 < f1) {  // next frame's source tile: in flight during this frame's pixels
-                RS_LOAD_TILE(frame + arena_stride);
+            if (f + ahead < f1) {  // a later frame's source tile: in flight during this frame's pixels
+                RS_LOAD_TILE_INTO(frame + (uint64_t)ahead * arena_stride, r0_, r1_, r2_, r3_);
             }
             uint32_t o[RPT];
 #pragma unroll
@@ -425,7 +436,16 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
 #ifdef HT_RS_PHASES
             rs_iter++;
 #endif
+            frame += arena_stride;
+        };
+#if HT_RS_PF2
+        for (uint32_t f = f0; f < f1; f += 2) {
+            step(v0, v1, v2, v3, f, 2u);
+            if (f + 1 < f1) step(w0, w1, w2, w3, f + 1, 2u);
         }
+#else
+        for (uint32_t f = f0; f < f1; f++) step(v0, v1, v2, v3, f, 1u);
+#endif
         return;
     }
     // nothing drawn in this tile (transparent black), or a source span larger than the LDS window (ratios > 2.3: the

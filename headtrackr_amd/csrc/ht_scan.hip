@@ -348,21 +348,41 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             // compacted: tools/sim_scan_lds.py counts 6.6 % fewer LDS cycles for the whole kernel with contiguous rows.
             const uint32_t nbat = (n_in + 63u) >> 6, per = HT_TILE_BLOCKASSIGN ? (nbat + 3u) >> 2 : 0u;
             const uint32_t b_lo = HT_TILE_BLOCKASSIGN ? wv * per : 0u, b_hi = HT_TILE_BLOCKASSIGN ? min(b_lo + per, nbat) : nbat;
+#ifndef HT_TILE_PAIR
+#define HT_TILE_PAIR 1
+#endif
+            // pair mode: a lane evaluates the two ADJACENT windows (X', X'+1) of a pass's 128 consecutive ids from shared aligned dword
+            // reads (ht_gen_stage_0_pair: 30 LDS reads per pair instead of 2 x 22; stage 0 is LDS-throughput bound)
+            constexpr bool PAIR = HT_TILE_PAIR && HT_TILE_BLOCKASSIGN && PITCH0 == HT_GEN_PAIR_PITCH0 && P12_BASE == HT_GEN_PAIR_P12;
             for (uint32_t bt = b_lo; bt < b_hi; bt += (HT_TILE_BLOCKASSIGN ? 2u : 8u)) {
                 uint32_t id[2], xx[2], yy[2], Fv[2];
                 bool valid[2];
+                if (PAIR) {
+                    const uint32_t lim = min(b_hi * 64u, n_in);
+                    id[0] = bt * 64u + 2u * lane;
+                    const bool in0 = id[0] < lim;  // ids come in even / odd pairs of one row: tw2 is even
+                    id[0] = in0 ? id[0] : 0u;
+                    id[1] = id[0] + 1u;
+                    yy[0] = yy[1] = __umul24(id[0], S.div_magic) >> 20;
+                    xx[0] = id[0] - __umul24(yy[0], (uint32_t)S.tw2);
+                    xx[1] = xx[0] + 1u;
+                    valid[0] = in0 && xx[0] < (uint32_t)tw;
+                    valid[1] = in0 && xx[1] < (uint32_t)tw;
+                    ht_gen_stage_0_pair(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), Fv[0], Fv[1]);
+                } else {
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const uint32_t bu = HT_TILE_BLOCKASSIGN ? bt + (uint32_t)u : bt + 4u * (uint32_t)u + wv;
-                    const uint32_t pos = bu * 64u + lane;
-                    valid[u] = bu < b_hi && pos < n_in;
-                    id[u] = valid[u] ? pos : 0u;
-                    yy[u] = __umul24(id[u], S.div_magic) >> 20;  // 24-bit multiplies: v_mul_lo_u32 is quarter rate (id < 2^11, magic < 2^18)
-                    xx[u] = id[u] - __umul24(yy[u], (uint32_t)S.tw2);
-                    valid[u] = valid[u] && xx[u] < (uint32_t)tw;
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t bu = HT_TILE_BLOCKASSIGN ? bt + (uint32_t)u : bt + 4u * (uint32_t)u + wv;
+                        const uint32_t pos = bu * 64u + lane;
+                        valid[u] = bu < b_hi && pos < n_in;
+                        id[u] = valid[u] ? pos : 0u;
+                        yy[u] = __umul24(id[u], S.div_magic) >> 20;  // 24-bit multiplies: v_mul_lo_u32 is quarter rate (id < 2^11, magic < 2^18)
+                        xx[u] = id[u] - __umul24(yy[u], (uint32_t)S.tw2);
+                        valid[u] = valid[u] && xx[u] < (uint32_t)tw;
+                    }
+                    if (!HT_TILE_BLOCKASSIGN && bt + wv >= nbat) break;  // round-robin: this wavefront's batches are exhausted
+                    ht_gen_stage_0_x2(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), lds + (valid[1] ? 2u * (yy[1] * PITCH0 + xx[1]) : 0u), Fv[0], Fv[1]);
                 }
-                if (!HT_TILE_BLOCKASSIGN && bt + wv >= nbat) break;  // round-robin: this wavefront's batches are exhausted
-                ht_gen_stage_0_x2(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), lds + (valid[1] ? 2u * (yy[1] * PITCH0 + xx[1]) : 0u), Fv[0], Fv[1]);
                 bool pass[2];
                 pass[0] = (Fv[0] >= HT_GEN_FMIN[0]) & valid[0];
                 pass[1] = (Fv[1] >= HT_GEN_FMIN[0]) & valid[1];

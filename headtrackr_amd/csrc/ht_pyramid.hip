@@ -791,8 +791,12 @@ extern "C" int ht_debug_rs_phases(unsigned long long *out16, int reset) {
             if (!t[2] || !t[6] || t[6] < t[2] || t[6] - t[2] > (1ull << 24)) continue;  // empty or torn slot
             for (int i = 3; i <= 6; i++)
                 if (t[i] >= t[i - 1]) out16[i] += t[i] - t[i - 1], out16[8 + i]++;
-            if (it == 0 && h[sl][0][1] && t[2] >= h[sl][0][1]) out16[2] += t[2] - h[sl][0][1], out16[8 + 2]++;
-            if (it == 0 && h[sl][0][0] && h[sl][0][1] >= h[sl][0][0]) out16[1] += h[sl][0][1] - h[sl][0][0], out16[8 + 1]++;
+            // setup of the workgroup: only if stamps 0, 1 and the first loop top are in order and close together (different launches
+            // that hashed to the same slot overwrite each other's stamps)
+            if (it == 0 && h[sl][0][0] && h[sl][0][0] <= h[sl][0][1] && h[sl][0][1] <= t[2] && t[2] - h[sl][0][0] < (1ull << 16)) {
+                out16[1] += h[sl][0][1] - h[sl][0][0], out16[8 + 1]++;
+                out16[2] += t[2] - h[sl][0][1], out16[8 + 2]++;
+            }
         }
     if (const char *e = std::getenv("HT_RS_SUBSTAMPS")) {  // setup sub-phases: entry -> record/extent inputs -> extents -> addresses -> loads issued -> taps -> barrier
         (void)e;

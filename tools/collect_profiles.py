@@ -55,6 +55,10 @@ for wl in ("c2", "c4", "c3"):
             t[short[k]] = round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
     if t:
         traffic[wl] = t
+for name in ("tile_timeline_c2.txt", "tile_timeline_c4.txt", "rs_phases_c2.txt", "rs_phases_c4.txt"):  # shader-clock phase timelines (tools/gpu_tile_timeline.py, gpu_rs_phases.py)
+    src = os.path.join(G, name)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
 for name in ("default", "c5"):
     bj = os.path.join(G, f"bench_{name}.json")
     if os.path.exists(bj):

@@ -25,4 +25,10 @@ for wl in c2 c4 c3; do
   echo "pmc $wl done"
 done
 fi
+# shader-clock phase timelines of the two big kernels (instrumented builds: alt/tltl.so = -DHT_TILE_TIMELINE, alt/rsph.so = -DHT_RS_PHASES)
+LIB=headtrackr_amd/libheadtrackr_hip.so
+cp $LIB /tmp/final_base.so
+if [ -f alt/tltl.so ]; then cp alt/tltl.so $LIB; for wl in c2 c4; do timeout 300 python tools/gpu_tile_timeline.py $wl > $OUT/tile_timeline_$wl.txt 2>&1; done; fi
+if [ -f alt/rsph.so ]; then cp alt/rsph.so $LIB; for wl in c2 c4; do timeout 300 python tools/gpu_rs_phases.py $wl > $OUT/rs_phases_$wl.txt 2>&1; done; fi
+cp /tmp/final_base.so $LIB
 echo done

@@ -33,4 +33,4 @@ names = {1: "setup + first loads + barrier", 2: "stamp 1 -> first loop top", 3: 
 print(f"{wl}: {int(cnt[3])} frame iterations sampled, mean iteration {sum(cyc[3:7]) / max(cnt[3], 1):.0f} cycles")
 for p in range(1, 7):
     if cnt[p] > 0:
-        print(f"  {names[p]:30s} visits {int(cnt[p]):8d}  mean {cyc[p] / cnt[p]:8.0f} cycles  {100 * cyc[p] / tot:5.1f} % of all workgroup-cycles")
+        print(f"  {names[p]:30s} samples {int(cnt[p]):8d}  mean {cyc[p] / cnt[p]:8.0f} cycles")

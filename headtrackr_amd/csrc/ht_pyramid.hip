@@ -312,6 +312,10 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
     __shared__ RsTap s_col[RS_TW], s_row[TH];
     uint32_t gidx, blk;
     if (!xcd_item(blocks_per_frame, ngroups, &gidx, &blk)) return;
+#ifndef HT_RS_PRIO
+#define HT_RS_PRIO 1  // measured: 1 -> resample -1 % / -1.4 %; 2 (also every frame's LDS write + load issue ahead of the pixel arithmetic): no better
+#endif
+    if (HT_RS_PRIO) __builtin_amdgcn_s_setprio(3);  // record, extent, first loads, tap tables: ahead of other wavefronts' pixel arithmetic
 #ifdef HT_RS_PHASES
     const uint32_t rs_slot = (blockIdx.x ^ (blocks_per_frame * 2654435761u)) & 16383u;  // different launches mostly land in different slots
     uint32_t rs_iter = 0;
@@ -381,6 +385,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
         RS_SUB(4);
         __syncthreads();
+        if (HT_RS_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         RS_STAMP(1);
         int ia[4], ib[4];
         const RsTap *coltap[4];
@@ -409,6 +414,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
             if (f + ahead < f1) {  // a later frame's source tile: in flight during this frame's pixels
                 RS_LOAD_TILE_INTO(frame + (uint64_t)ahead * arena_stride, r0_, r1_, r2_, r3_);
             }
+            if (HT_RS_PRIO >= 2) __builtin_amdgcn_s_setprio(0);  // the pixel arithmetic yields to wavefronts that are staging / issuing loads
             uint32_t o[RPT];
 #pragma unroll
             for (int q = 0; q < RPT; q++) {
@@ -431,6 +437,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
                 const int y = yt + 16 * q;
                 if (q < np && y < ch && x0 < dst_stride) *reinterpret_cast<uint32_t *>(frame + (doff + (uint32_t)(16 * q * dst_stride))) = o[q];
             }
+            if (HT_RS_PRIO >= 2) __builtin_amdgcn_s_setprio(3);
             if (f + 1 < f1) __syncthreads();  // every wave is done reading this frame's tile
             RS_STAMP(6);
 #ifdef HT_RS_PHASES

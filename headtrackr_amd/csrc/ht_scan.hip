@@ -230,6 +230,11 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 #ifdef HT_TILE_TIMELINE
     unsigned long long tl_prev = __builtin_readcyclecounter();
 #endif
+#ifndef HT_TILE_PRIO
+#define HT_TILE_PRIO 1  // measured: 1 -> scan_tiles -2.1 % (C2) / -2.9 % (C4); 2 (also the sparse stages at high priority): the same
+#endif
+    // wave priority: the short dependent chain that gets the tile's loads out runs ahead of other wavefronts' stage-0 bursts
+    if (HT_TILE_PRIO) __builtin_amdgcn_s_setprio(3);
 
     // ---- stage the three planes into LDS --------------------------------------------------------------------
     // All global loads of a thread are issued before the first LDS write (fixed trip counts, predicated), so one
@@ -314,6 +319,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     if (tid == 0) s_nout = 0;
     if (WAVEQ && tid < 192u) SF(tid >> 6, tid & 63u) = 0u;
     __syncthreads();
+    if (HT_TILE_PRIO) __builtin_amdgcn_s_setprio(0);
     TL_STAMP(0);
 
     // ---- cascade with per-stage compaction -------------------------------------------------------------------
@@ -400,6 +406,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             if (tid == 0 && my_stats) atomicAdd(&my_stats[0], (unsigned long long)(uint32_t)(tw * th));
         }
         // -- stages 1.. on the wavefront's own queue, until the tile is down to one wavefront of windows
+        if (HT_TILE_PRIO == 3) __builtin_amdgcn_s_setprio(3);
         int s = 1;
         uint32_t total = 0;
         uint4 cn = make_uint4(0u, 0u, 0u, 0u);
@@ -441,6 +448,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             }
             wq = out;
         }
+        if (HT_TILE_PRIO) __builtin_amdgcn_s_setprio(HT_TILE_PRIO > 1 ? 3 : 0);
         if (gather) {
             // -- <= 64 windows left in the tile: lane = survivor in every wavefront, stages in four feature slices
             const uint32_t o1 = cn.x, o2 = o1 + cn.y, o3 = o2 + cn.z;

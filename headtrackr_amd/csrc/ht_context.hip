@@ -237,6 +237,7 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         }
     }
     if (const char *e = getenv("HT_DEBUG_RS_MINWG")) c->rs_min_wgs = std::max(1, atoi(e));  // measurement knob
+    if (const char *e = getenv("HT_DEBUG_RS_K")) c->dbg_rs_k = atoi(e);
     if (const char *e = getenv("HT_DEBUG_RS_GROUP")) {  // measurement knob
         const int v = atoi(e);
         if (v >= 1 && v <= 64) c->rs_group = v;

@@ -260,6 +260,7 @@ struct ht_ctx {
     bool deep_attr_set = false;              // k_scan_deep_lds: > 64 KB dynamic LDS enabled on this context's device
     bool tail_table = true;  // k_resample_tail with host tap tables (false: the round-1 binary64 tail, HT_DEBUG_RS_TAILTABLE=0)
     int rs_min_wgs = 2048;  // ... but never fewer workgroups per launch than this (HT_DEBUG_RS_MINWG)
+    int dbg_rs_k = 0;  // HT_DEBUG_RS_K: frames per k_resample workgroup, forced (any value)
     int rs_group = 8;  // k_resample: frames per workgroup at most (HT_DEBUG_RS_GROUP)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
 

@@ -743,6 +743,7 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         while (K * 2 <= (uint32_t)c->rs_group && (uint64_t)c->gen_blocks[g] * ((uint32_t)c->nframes / (K * 2)) >= (uint64_t)c->rs_min_wgs &&
                (uint32_t)c->nframes % (K * 2 * 8) == 0)
             K *= 2;
+        if (c->dbg_rs_k > 0) K = (uint32_t)std::min(c->dbg_rs_k, std::max(1, c->nframes));  // HT_DEBUG_RS_K: measurement knob
         const uint32_t ngroups = ((uint32_t)c->nframes + K - 1) / K;
         const dim3 rgrid((c->gen_blocks[g] * ngroups + 7u) & ~7u);
         hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,

@@ -13,9 +13,11 @@
 //     four quarter-res variants interleaved into one half-step grid in the odd bytes of the plane-1 cells.  Then
 //     every window has ONE base address B = 2*(Y'*P + X') and every feature point is base + a per-feature constant,
 //     so the inner loop is {s_load feature (uniform), v_add, ds_read_u8, v_min/v_max}; adjacent lanes (adjacent X')
-//     read LDS at a 2-byte stride on every plane: conflict-free.  Windows that pass a stage are compacted
-//     (ballot + LDS counter) so later stages run on dense lanes.  Per-lane sums are sequential binary64 adds in the
-//     reference's order, hence bit-exact.
+//     read LDS at a 2-byte stride on every plane: conflict-free.  Windows that pass a stage are compacted so later stages
+//     run on dense lanes.  Built-in cascade: the first 8 stages are generated straight-line code with exact integer decisions
+//     and run "wave-private" (every wavefront owns the survivors of its windows: no atomics, no barriers; see the comment in
+//     the kernel); other cascades and later stages: table-driven, shared queue, per-lane sequential binary64 sums in the
+//     reference's order.  Both are bit-exact.
 //   * k_scan_deep — survivors of the first `split` stages (a fraction of a percent of all windows) go through a
 //     global queue to one wavefront per window with the stage's features spread across lanes.  Stage decisions use
 //     exact integer sums of alpha*1e8 (the trained alphas/thresholds are 8-digit decimals; a different summation
@@ -159,37 +161,21 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                                                    uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
                                                    HtCounters *__restrict__ ctr, unsigned long long *__restrict__ stats) {
     __shared__ __attribute__((aligned(16))) uint8_t lds[LDS_TILE_BYTES];
-#ifndef HT_TILE_INPLACE
-#define HT_TILE_INPLACE 1
-#endif
-    // survivor queue(s) of window ids.  In-place mode: ONE queue, stage s compacts it onto itself (a thread reads its entry,
-    // the workgroup synchronises, then survivors are written to the front) — 4 KB less LDS per workgroup = 5 instead of
-    // 4 workgroups per CU.
-    constexpr int NQ = HT_TILE_INPLACE ? 1 : 2;
-    constexpr int QX = HT_TILE_INPLACE ? 0 : 1;  // cur ^ QX = index of the output queue
-#ifndef HT_TILE_QIN12
-#define HT_TILE_QIN12 1
-#endif
-#if HT_TILE_QIN12 && HT_TILE_INPLACE
-    // The unified-base layout gives the plane-1 / plane-2 rows a pitch of 2 * PITCH0 = 304 bytes of which only the first 160
-    // hold cells: the in-place survivor queue lives in the unused tail of those rows (64 u16 entries per row, 43 rows = 2752 >=
-    // MAXWIN) instead of 4 KB of its own — 26.4 KB of LDS per workgroup = 6 workgroups per CU instead of 5.
+    // Survivor queue of window ids, compacted in place (a thread reads its entry, the workgroup synchronises, then survivors are
+    // written to the front).  The unified-base layout gives the plane-1 / plane-2 rows a pitch of 2 * PITCH0 = 304 bytes of which only
+    // the first 160 hold cells: the queue lives in the unused tail of those rows (64 u16 entries per row, 43 rows = 2752 >= MAXWIN)
+    // instead of 4 KB of its own — 26.2 KB of LDS per workgroup = 6 workgroups per CU.
     static_assert(G_PITCH - 160 >= 128 && GH * 64 >= MAXWIN, "queue does not fit the row tails");
-#define QB(qi_, i_) (*reinterpret_cast<uint16_t *>(&lds[P12_BASE + 160 + ((uint32_t)(i_) >> 6) * G_PITCH + (((uint32_t)(i_)&63u) << 1)]))
-#else
-    __shared__ uint16_t qbuf[NQ][MAXWIN];
-#define QB(qi_, i_) (qbuf[qi_][i_])
-#endif
+#define QB(qi_, i_) (*reinterpret_cast<uint16_t *>(&lds[P12_BASE + 160 + ((uint32_t)(i_) >> 6) * G_PITCH + (((uint32_t)(i_)&63u) << 1)]))  // qi_: always 0 (one queue)
     __shared__ uint32_t s_nout;
     __shared__ uint32_t s_qbase;
-    __shared__ uint32_t s_F[64];  // sparse phase: per-survivor integer stage sums assembled from the 4 waves' slices
 #ifndef HT_TILE_WAVEQ
 #define HT_TILE_WAVEQ 1
 #endif
 #ifndef HT_TILE_MERGE_FROM
 #define HT_TILE_MERGE_FROM 2  // the first stage after which the wavefronts compare their survivor counts
 #endif
-#if HT_TILE_WAVEQ && HT_TILE_QIN12 && HT_TILE_INPLACE
+#if HT_TILE_WAVEQ
     // Wave-private layout of the same row tails (see "wave-private cascade" below): rows [8w, 8w + 8) = wavefront w's queue of
     // window ids (a wavefront enumerates at most MAXWIN / 4 = 512 windows), rows 32-37 = three buffers of 64 per-survivor integer
     // stage sums (36 dwords of tail per row: 32 used), row 38 = the wavefronts' survivor counts (two parities x 4).
@@ -199,12 +185,10 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 #define SF(b_, l_) (*reinterpret_cast<uint32_t *>(&lds[P12_BASE + 160 + (4 * WQ_ROWS + 2 * (b_) + ((l_) >> 5)) * G_PITCH + (((l_)&31u) << 2)]))
 #define SCNT(p_) (reinterpret_cast<uint32_t *>(&lds[P12_BASE + 160 + (4 * WQ_ROWS + 6) * G_PITCH + (p_) * 16]))
     constexpr bool WAVEQ = GEN && NT == 256;
-    constexpr bool LGEN = false;  // the shared-queue code below keeps the table-driven stages only (it runs the stages past the generated ones)
 #else
     constexpr bool WAVEQ = false;
-    constexpr bool LGEN = GEN;
 #define QW(w_, e_) QB(0, 0)
-#define SF(b_, l_) s_F[l_]
+#define SF(b_, l_) (*SCNT(0))
 #define SCNT(p_) (&s_qbase)
     constexpr int WQ_CAP = 0;
 #endif
@@ -335,8 +319,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     // read per stage, no queue.  Window sets and stage decisions are exactly those of the shared-queue code below, which still
     // serves other cascades, the stages past the generated ones and the hand-off to k_scan_deep.
     uint32_t n_in = (uint32_t)(S.tw2 * th);  // stage 0 enumerates id = Y'*tw2 + X' (X' >= tw is masked off)
-    uint32_t qoff = 0;                        // start of the live entries inside qbuf[cur]
-    int cur = 0;
+    uint32_t qoff = 0;                        // start of the live entries inside the queue
     bool pushed = (split >= nstages);
     int s_first = 0;
     const int wq_lim = min(min(split, nstages - 1), (int)HT_GEN_STAGES);  // stages [0, wq_lim) run wave-private
@@ -501,60 +484,8 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             n_in = total;
         }
         s_first = s;
-    } else
-    // ---- stage 0, generated code, two windows per thread per iteration: every window of the tile runs it (74 % of
-    // them end here), so it gets its own loop: the two independent evaluations give the scheduler twice the LDS reads
-    // to keep in flight per wait.
-    if (LGEN && stop_stage != 0 && split > 0 && nstages > 1) {
-        const HtDevStage st0 = stages[0];
-        for (uint32_t base = 0; base < n_in; base += 2 * NT) {
-            uint32_t id[2], xx[2], yy[2], Fv[2];
-            bool valid[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const uint32_t pos = base + u * NT + tid;
-                valid[u] = pos < n_in;
-                id[u] = valid[u] ? pos : 0u;
-                yy[u] = __umul24(id[u], S.div_magic) >> 20;  // 24-bit multiplies: v_mul_lo_u32 is quarter rate (id < 2^11, magic < 2^18)
-                xx[u] = id[u] - __umul24(yy[u], (uint32_t)S.tw2);
-                valid[u] = valid[u] && xx[u] < (uint32_t)tw;
-            }
-            // a wavefront whose 64 + 64 windows all lie beyond the tile's last window has nothing to evaluate (wave-uniform branch)
-            if (base + (tid & ~63u) >= n_in) continue;
-            ht_gen_stage_0_x2(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), lds + (valid[1] ? 2u * (yy[1] * PITCH0 + xx[1]) : 0u), Fv[0], Fv[1]);
-            // Both decisions first, the (rare) tie branches after them: the arithmetic of both windows stays in the basic block of
-            // its loads.  hipcc narrows the byte min / max to 16-bit operations and, for a value that crosses a block boundary, no
-            // longer knows that ds_read_u8 zero-extends: a v_and 0xff per pixel, +40 % VALU instructions in this loop.
-            bool pass[2];
-            pass[0] = (Fv[0] >= HT_GEN_FMIN[0]) & valid[0];
-            pass[1] = (Fv[1] >= HT_GEN_FMIN[0]) & valid[1];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                if (valid[u] && (Fv[u] == HT_GEN_FTIE[0] || force_exact))  // exact tie: the sequential binary64 sum decides
-                    pass[u] = !(eval_stage_lds(lds, 2u * (yy[u] * PITCH0 + xx[u]), feats + st0.first, st0.count) < st0.threshold);
-            }
-            // one queue reservation per wave for both windows (one LDS atomic round trip instead of two, no ds_bpermute)
-            const unsigned long long m0 = __ballot(pass[0]), m1 = __ballot(pass[1]);
-            if (m0 | m1) {
-                const uint32_t c0 = __popcll(m0), c1 = __popcll(m1);
-                uint32_t b0 = 0;
-                if (lane == 0) b0 = atomicAdd(&s_nout, c0 + c1);
-                b0 = __builtin_amdgcn_readfirstlane(b0);
-                if (pass[0]) QB(cur ^ QX, b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) = (uint16_t)id[0];
-                if (pass[1]) QB(cur ^ QX, b0 + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) = (uint16_t)id[1];
-            }
-        }
-        if (tid == 0 && my_stats) atomicAdd(&my_stats[0], (unsigned long long)(uint32_t)(tw * th));
-        __syncthreads();
-        n_in = s_nout;
-        __syncthreads();
-        if (tid == 0) s_nout = 0;
-        cur ^= QX;
-        TL_STAMP(1);
-        if (n_in == 0) return;
-        __syncthreads();
-        s_first = 1;
     }
+    // ---- shared-queue cascade, table-driven stages: other cascades from stage 0, the built-in one past its generated stages
     for (int s = s_first; s < nstages; s++) {
         if (s == stop_stage) return;  // measurement knob (HT_DEBUG_STOP_STAGE): results are incomplete when set
         const HtDevStage st = stages[s];
@@ -569,7 +500,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             const uint32_t room = qb < queue_cap ? queue_cap - qb : 0u;
             const uint32_t npush = min(n_in, room);
             for (uint32_t i = tid; i < npush; i += NT) {
-                const uint32_t id = QB(cur, qoff + i);
+                const uint32_t id = QB(0, qoff + i);
                 const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
                 const uint32_t ax = (uint32_t)X0 + xx, ay = (uint32_t)Y0 + yy;
                 HtQueueEntry e;
@@ -590,75 +521,12 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         }
         const HtTileFeature *F = feats + st.first;
         const bool last = (s == nstages - 1);
-        if (LGEN && NT == 256 && s < HT_GEN_STAGES && n_in <= 64u) {
-            // sparse phase: at most one wavefront of survivors left.  Instead of one wave walking the whole stage while
-            // three idle at the barrier, every wave takes the features k % 4 == wave for ALL survivors and the partial
-            // integer sums meet in LDS (exact: integer addition is order-free) — the stage takes a quarter of the time,
-            // so the tile's LDS and wave slots are released sooner.
-            const uint32_t wv = tid >> 6;
-            if (tid < 64u) s_F[tid] = 0u;
-            __syncthreads();
-            const bool valid = lane < n_in;
-            const uint32_t id = valid ? (uint32_t)QB(cur, qoff + lane) : 0u;
-            const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
-            const uint32_t B = 2u * (yy * PITCH0 + xx);
-            const uint32_t part = ht_gen_stage_slice(s, (int)wv, lds + B);
-            if (valid && part) atomicAdd(&s_F[lane], part);
-            __syncthreads();
-            if (wv == 0) {
-                const uint32_t Fv = s_F[lane];
-                bool pass = valid && Fv >= HT_GEN_FMIN[s];
-                if (valid && (Fv == HT_GEN_FTIE[s] || force_exact))  // exact tie with the threshold: let the sequential binary64 sum decide
-                    pass = !(eval_stage_lds(lds, B, F, st.count) < st.threshold);
-                const unsigned long long m = __ballot(pass);
-                const uint32_t pre = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (pass) QB(cur ^ QX, pre) = (uint16_t)id;
-                if (lane == 0) s_nout = (uint32_t)__popcll(m);
-            }
-        } else if (LGEN && s == 1 && n_in > (uint32_t)NT) {
-            // stage 1 typically still has ~1.7 survivors per thread: two windows per thread per pass like stage 0 (twice
-            // the LDS reads in flight per wait, half the passes, barriers and queue reservations)
-            for (uint32_t base = 0; base < n_in; base += 2 * NT) {
-                uint32_t id[2], Bv[2], Fv[2];
-                bool valid[2], pass[2];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const uint32_t pos = base + u * NT + tid;
-                    valid[u] = pos < n_in;
-                    id[u] = valid[u] ? (uint32_t)QB(cur, qoff + pos) : 0u;
-                }
-                if (HT_TILE_INPLACE) __syncthreads();  // both entries are in registers before survivors overwrite the queue
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const uint32_t yy = __umul24(id[u], S.div_magic) >> 20, xx = id[u] - __umul24(yy, (uint32_t)S.tw2);
-                    Bv[u] = 2u * (yy * PITCH0 + xx);
-                }
-                if (base + (tid & ~63u) >= n_in) continue;  // no survivor on this wavefront (after the barrier: every wave hits it)
-                ht_gen_stage_1_x2(lds + (valid[0] ? Bv[0] : 0u), lds + (valid[1] ? Bv[1] : 0u), Fv[0], Fv[1]);
-                pass[0] = (Fv[0] >= HT_GEN_FMIN[1]) & valid[0];
-                pass[1] = (Fv[1] >= HT_GEN_FMIN[1]) & valid[1];
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    if (valid[u] && (Fv[u] == HT_GEN_FTIE[1] || force_exact))  // exact tie: the sequential binary64 sum decides
-                        pass[u] = !(eval_stage_lds(lds, Bv[u], F, st.count) < st.threshold);
-                }
-                const unsigned long long m0 = __ballot(pass[0]), m1 = __ballot(pass[1]);
-                if (m0 | m1) {
-                    const uint32_t c0 = __popcll(m0), c1 = __popcll(m1);
-                    uint32_t b0 = 0;
-                    if (lane == 0) b0 = atomicAdd(&s_nout, c0 + c1);
-                    b0 = __builtin_amdgcn_readfirstlane(b0);
-                    if (pass[0]) QB(cur ^ QX, b0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u))) = (uint16_t)id[0];
-                    if (pass[1]) QB(cur ^ QX, b0 + c0 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))) = (uint16_t)id[1];
-                }
-            }
-        } else
         for (uint32_t base = 0; base < n_in; base += NT) {
             const uint32_t pos = base + tid;
             bool valid = pos < n_in;
             uint32_t id = 0;
-            if (valid) id = (s == 0) ? pos : (uint32_t)QB(cur, qoff + pos);
-            if (HT_TILE_INPLACE && s > 0) __syncthreads();  // every entry of this chunk is in a register before survivors overwrite the queue
+            if (valid) id = (s == 0) ? pos : (uint32_t)QB(0, qoff + pos);
+            if (s > 0) __syncthreads();  // every entry of this chunk is in a register before survivors overwrite the queue
             // Survivors are compacted, so the waves behind the last survivor have no valid lane: they skip the stage body
             // (wave-uniform branch; the barrier above and the one after the loop are still hit by every wave).  With 65..255
             // survivors — the usual case in stages 2-3 — up to three of the four waves used to walk the whole stage on dead lanes,
@@ -667,18 +535,8 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
             valid = valid && xx < (uint32_t)tw;
             const uint32_t B = 2u * (yy * PITCH0 + xx);
-            double sum = 0.0;
-            bool pass;
-            if (LGEN && s < HT_GEN_STAGES) {
-                // generated straight-line stage: exact integer decision (see tools/gen_cascade_code.py)
-                const uint32_t Fv = ht_gen_stage(s, lds + (valid ? B : 0u));
-                pass = valid && Fv >= HT_GEN_FMIN[s];
-                if (valid && (Fv == HT_GEN_FTIE[s] || force_exact))  // exact tie with the threshold: let the sequential binary64 sum decide
-                    pass = !(eval_stage_lds(lds, B, F, st.count) < st.threshold);
-            } else {
-                sum = eval_stage_lds(lds, valid ? B : 0u, F, st.count);
-                pass = valid && !(sum < st.threshold);  // ccv.js:222
-            }
+            const double sum = eval_stage_lds(lds, valid ? B : 0u, F, st.count);
+            const bool pass = valid && !(sum < st.threshold);  // ccv.js:222
             const unsigned long long m = __ballot(pass);
             if (m) {
                 const uint32_t cnt = __popcll(m);
@@ -687,7 +545,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 if (!last) {
                     if (lane == 0) b0 = atomicAdd(&s_nout, cnt);
                     b0 = __builtin_amdgcn_readfirstlane(b0);
-                    if (pass) QB(cur ^ QX, b0 + pre) = (uint16_t)id;
+                    if (pass) QB(0, b0 + pre) = (uint16_t)id;
                 } else {
                     if (lane == 0) b0 = atomicAdd(&ctr->nhits, cnt);
                     b0 = __builtin_amdgcn_readfirstlane(b0);
@@ -713,7 +571,6 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
         n_in = s_nout;
         __syncthreads();
         if (tid == 0) s_nout = 0;
-        cur ^= QX;
         qoff = 0;
         TL_STAMP(1 + min(s, 8));
         if (n_in == 0) return;

@@ -227,7 +227,10 @@ __device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int
         }
         return o;
     }
-    uint32_t need = 0;
+    // v_cvt_pk_u8_f32 converts and inserts a byte in one instruction (its input is already integral: no rounding-mode question), and
+    // the distances to the nearest rounding boundary are tested once per 4 pixels (max of the four |v - r|) instead of with a compare +
+    // select + or per pixel.
+    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (k < npx) {
@@ -237,14 +240,15 @@ __device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int
             const float bot = __builtin_fmaf(ctf[k], p11 - p10, p10);
             const float v = __builtin_fmaf(rtf, bot - top, top);
             const float r = __builtin_rintf(v);
-            if (__builtin_fabsf(v - r) >= 0.5f - RS_EPS) need |= 1u << k;
-            o |= (uint32_t)(int)r << (8 * k);
+            d[k] = v - r;
+            o = __builtin_amdgcn_cvt_pk_u8_f32(r, k, o);
         }
     }
-    if (need) {  // rare: the declared binary64 sequence for the pixels next to a rounding boundary
+    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[0]), __builtin_fabsf(d[1])), __builtin_fmaxf(__builtin_fabsf(d[2]), __builtin_fabsf(d[3])));
+    if (dmax >= 0.5f - RS_EPS) {  // rare: the declared binary64 sequence for the pixels next to a rounding boundary
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (need & (1u << k)) {
+            if (k < npx && __builtin_fabsf(d[k]) >= 0.5f - RS_EPS) {
                 o &= ~(0xffu << (8 * k));
                 o |= rs_pixel_f64(row + ia[k], row + ib[k], cu(k), ct(k), ru, rt) << (8 * k);
             }

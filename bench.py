@@ -364,32 +364,58 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
             x += int(walk[2 * (f * NV + v)] % 7) - 3
             y += int(walk[2 * (f * NV + v) + 1] % 7) - 3
     dev_vers = [torch.from_numpy(vers[v]).cuda() for v in range(NV)]
-    ctx = Context(device=local)
-    ctx.set_geometry(W, H, nf)
-    ctx.bind_device(dev_vers[0].data_ptr(), nf, W * H * 4)
-    ctx.camshift_reserve(nf)
+    # Two contexts take the steps in turn (own HIP streams, own tracker states): while one batch of streams is in its 60 track()
+    # calls (one launch, one workgroup per stream: half of every CU idle) the next step's detect runs on the other context.
+    # --pipeline 1 keeps the steps strictly in turn.
+    depth = 1 if a.pipeline == 1 else 2
+    ctxs = []
+    for _ in range(depth):
+        cx = Context(device=local)
+        cx.set_geometry(W, H, nf)
+        cx.bind_device(dev_vers[0].data_ptr(), nf, W * H * 4)
+        cx.camshift_reserve(nf)
+        ctxs.append(cx)
+    ctx = ctxs[0]
     seq_ptrs = [dev_vers[(it + 1) % NV].data_ptr() for it in range(CALLS)]
     state = {}
+    pending = []  # contexts whose track sequence is enqueued but not collected
 
-    def step():
-        ctx.detect_enqueue(a.flags)
-        hits, counts = ctx.detect_collect(cap=1 << 17)
-        best = ctx.best_faces(hits, counts, 1)  # facetrackr.js:147-175 for the whole batch
+    def finish(cx):
+        state["tracked"] = cx.camshift_sequence_collect(nf, CALLS)  # the track objects of the 60th call
+
+    def step(i=0):
+        cx = ctxs[i % depth]
+        cx.detect_enqueue(a.flags)
+        if len(pending) == depth - 1 and pending:  # the other context's tracking result, while this detect runs
+            finish(pending.pop(0))
+        hits, counts = cx.detect_collect(cap=1 << 17)
+        best = cx.best_faces(hits, counts, 1)  # facetrackr.js:147-175 for the whole batch
         fl = np.floor(np.stack([best["x"], best["y"], best["width"], best["height"]], axis=1)).astype(np.int64)  # facetrackr.js:101-106
         rects = [tuple(fl[f]) if best["neighbors"][f] > 0 else (W // 4, H // 4, W // 2, H // 2) for f in range(nf)]
-        ctx.camshift_init(rects)
-        tracked = ctx.camshift_track_sequence(seq_ptrs, nf, calc_angles=True)  # 60 calls, one host call, last result fetched
-        state.update(best=best, tracked=tracked, rects=rects)
+        cx.camshift_init(rects)
+        cx.camshift_track_sequence(seq_ptrs, nf, calc_angles=True, fetch="none")  # 60 calls, one host call, enqueue only
+        pending.append(cx)
+        if depth == 1:
+            finish(pending.pop(0))
+        state.update(best=best, rects=rects)
 
-    for _ in range(max(warmup, 1)):
-        step()
+    def drain():
+        while pending:
+            finish(pending.pop(0))
+
+    for i in range(max(warmup, 1)):
+        step(i)
+    drain()
     env.fence()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
+    for i in range(steps):
+        step(i)
+    drain()
     env.fence()
     dt = env.max_over_ranks(time.perf_counter() - t0)
     total_frames = world * nf * steps * (CALLS + 1)  # every processed frame: 1 detected + 60 tracked per stream and step
+    for cx in ctxs[1:]:
+        cx.close()
     if rank != 0:
         ctx.close()
         return None
@@ -416,7 +442,8 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
         "value": round(total_frames / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "scaling": "weak",
         "config": {"workload": WORKLOAD_TEXT["c3"], "streams_per_gpu": nf, "track_calls_per_step": CALLS, "width": W, "height": H,
                    "frame_mix": "family F only: one vote-image face per stream, moved by a seeded <= 3 px walk over 4 frame versions",
-                   "host_calls_per_step": "ht_detect_enqueue/collect + ht_best_faces + ht_camshift_init_batch + ONE ht_camshift_track_sequence (60 calls)"},
+                   "steps_in_flight": depth,
+                   "host_calls_per_step": "ht_detect_enqueue/collect + ht_best_faces + ht_camshift_init_batch + ONE ht_camshift_track_sequence (60 calls) + ht_camshift_sequence_collect"},
         "roofline": dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
                          algorithmic_bytes_per_stream_call=round(b_track, 1), window_pixels_per_call=round(win_px_per_call, 1), streams_per_launch=nf,
                          calls_per_launch=round(CALLS / max(launches[dom], 1), 1), avg_launch_ms=round(per_launch[dom] * CALLS / max(launches[dom], 1), 5)),

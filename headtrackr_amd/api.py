@@ -224,17 +224,24 @@ class Context:
         return out
 
     def camshift_track_sequence(self, dev_ptrs, n: int, calc_angles: bool = True, first: int = 0, frame_stride: int | None = None,
-                                fetch: str = "last"):
+                                fetch: str = "last", keep_all: bool = False):
         """len(dev_ptrs) successive track() calls in one host call; call k reads the n device-resident frames at dev_ptrs[k].
-        fetch: "last" -> [n] track objects of the last call, "all" -> [calls, n], "none" -> enqueue only."""
+        fetch: "last" -> [n] track objects of the last call, "all" -> [calls, n], "none" -> enqueue only (camshift_sequence_collect
+        fetches later: the last call's objects, or every call's if keep_all)."""
         k = len(dev_ptrs)
         ptrs = (C.c_void_p * k)(*[int(p) for p in dev_ptrs])
         stride = frame_stride or self.width * self.height * 4
         if fetch == "none":
-            self._check(self._lib.ht_camshift_track_sequence(self._h, first, n, int(calc_angles), ptrs, k, stride, None, 0))
+            self._check(self._lib.ht_camshift_track_sequence(self._h, first, n, int(calc_angles), ptrs, k, stride, None, int(keep_all)))
             return None
         out = np.zeros((k, n) if fetch == "all" else (n,), dtype=native.CS_TRACKOBJ_DTYPE)
         self._check(self._lib.ht_camshift_track_sequence(self._h, first, n, int(calc_angles), ptrs, k, stride, out.ctypes.data, int(fetch == "all")))
+        return out
+
+    def camshift_sequence_collect(self, n: int, ncalls: int, fetch: str = "last"):
+        """Results of the last camshift_track_sequence(..., fetch="none"): waits for it ("last" -> [n], "all" -> [ncalls, n])."""
+        out = np.zeros((ncalls, n) if fetch == "all" else (n,), dtype=native.CS_TRACKOBJ_DTYPE)
+        self._check(self._lib.ht_camshift_sequence_collect(self._h, n, ncalls, int(fetch == "all"), out.ctypes.data))
         return out
 
     def camshift_stats(self, n: int, first: int = 0, reset: bool = True):

@@ -897,6 +897,16 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
     return HT_OK;
 }
 
+extern "C" ht_status ht_camshift_sequence_collect(ht_ctx *c, int32_t n, int32_t ncalls, int32_t out_all, ht_cs_trackobj *out) {
+    if (!c || !out || n <= 0 || ncalls <= 0) return HT_ERR_INVALID;
+    const size_t need = (size_t)n * (size_t)(out_all ? ncalls : 1);
+    if (!c->d_cs_seq_out || c->cs_seq_cap < need) return ht_fail(c, HT_ERR_STATE, "ht_camshift_sequence_collect: no sequence of this size was enqueued");
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipMemcpyAsync(out, c->d_cs_seq_out, need * sizeof(ht_cs_trackobj), hipMemcpyDeviceToHost, c->stream));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    return HT_OK;
+}
+
 extern "C" ht_status ht_camshift_stats(ht_ctx *c, int32_t first, int32_t n, uint64_t *window_pixels, uint64_t *calls, int32_t reset) {
     if (!c || n <= 0 || first < 0 || first + n > c->cs_streams) return HT_ERR_INVALID;
     HT_HIP(c, hipSetDevice(c->device));

@@ -196,6 +196,10 @@ ht_status ht_camshift_track_batch(ht_ctx *ctx, int32_t first, int32_t n, int32_t
  * the track objects of the LAST call (out_all == 0, n entries) or of every call (out_all != 0, ncalls*n entries, call-major). */
 ht_status ht_camshift_track_sequence(ht_ctx *ctx, int32_t first, int32_t n, int32_t calc_angles, const void *const *dev_frames,
                                      int32_t ncalls, size_t frame_stride, ht_cs_trackobj *out, int32_t out_all);
+/* Results of the last ht_camshift_track_sequence that was enqueued with out == NULL (same n / ncalls / out_all): waits for it and
+ * copies the track objects.  Lets a host overlap the tracking of one batch of streams with other work on another context
+ * (the reference's main.js:168-180 consumes the track object of frame k while the camera already delivers frame k+1). */
+ht_status ht_camshift_sequence_collect(ht_ctx *ctx, int32_t n, int32_t ncalls, int32_t out_all, ht_cs_trackobj *out);
 /* Measurement hook (B_track = 4*W*H + 4*sum of window areas): per stream, the pixels read by the window
  * moment passes (camshift.js:79-120 called from camshift.js:284-306) and the number of track() calls since the last reset. */
 ht_status ht_camshift_stats(ht_ctx *ctx, int32_t first, int32_t n, uint64_t *window_pixels, uint64_t *calls, int32_t reset);

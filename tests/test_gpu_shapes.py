@@ -126,8 +126,16 @@ def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
             c.bind_device(dev[(k + 1) % nv].ptr, n)
             one = c.camshift_track(n, calc_angles=True)
             assert one.tobytes() == got[k].tobytes(), k
+        # enqueue only + ht_camshift_sequence_collect == fetched in the same call (all calls, and the last one)
+        c.bind_device(dev[0].ptr, n)  # initTracker reads the bound frames
+        c.camshift_init(rects)
+        assert c.camshift_track_sequence([dev[(k + 1) % nv].ptr for k in range(calls)], n, calc_angles=True, fetch="none", keep_all=True) is None
+        assert c.camshift_sequence_collect(n, calls, fetch="all").tobytes() == got.tobytes()
+        c.camshift_init(rects)
+        c.camshift_track_sequence([dev[(k + 1) % nv].ptr for k in range(calls)], n, calc_angles=True, fetch="none")
+        assert c.camshift_sequence_collect(n, calls).tobytes() == got[calls - 1].tobytes()
         px, ncalls = c.camshift_stats(n, reset=True)
-        assert np.all(ncalls == 3) and np.all(px > 0)
+        assert np.all(ncalls == calls) and np.all(px > 0)  # initTracker resets the counters: the last enqueue-only sequence
     finally:
         c.close()
         for d in dev:

@@ -136,6 +136,17 @@ def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
         assert c.camshift_sequence_collect(n, calls).tobytes() == got[calls - 1].tobytes()
         px, ncalls = c.camshift_stats(n, reset=True)
         assert np.all(ncalls == calls) and np.all(px > 0)  # initTracker resets the counters: the last enqueue-only sequence
+        # more calls than one launch carries (64): the second launch continues where the first stopped
+        c.bind_device(dev[0].ptr, n)
+        c.camshift_init(rects)
+        longer = c.camshift_track_sequence([dev[(k + 1) % nv].ptr for k in range(calls + 6)], n, calc_angles=True, fetch="all")
+        assert longer[:calls].tobytes() == got.tobytes()
+        c.bind_device(dev[0].ptr, n)
+        c.camshift_init(rects)
+        c.camshift_track_sequence([dev[(k + 1) % nv].ptr for k in range(calls)], n, calc_angles=True)
+        for k in range(calls, calls + 6):
+            c.bind_device(dev[(k + 1) % nv].ptr, n)
+            assert c.camshift_track(n, calc_angles=True).tobytes() == longer[k].tobytes(), k
     finally:
         c.close()
         for d in dev:

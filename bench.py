@@ -220,7 +220,17 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
         cx.bind_device(dev.data_ptr(), nf, W * H * 4)
         ctxs.append(cx)
     ctx = ctxs[0]
-    rec_local = torch.zeros((nf_max, hd.RECORD_F64), dtype=torch.float64, device="cuda")
+    # the exchange step's buffers, one set per batch in flight: pinned host records -> device records -> gathered table.  Nothing in it
+    # blocks the host: the copy is asynchronous, the collective is enqueued on RCCL's stream, and a set is only reused `depth` steps later
+    # (its event is checked first — by then it has long completed).
+    gather_on = world > 1 or os.environ.get("HT_BENCH_FORCE_GATHER") == "1"  # the env knob exercises this path on a 1-GPU box
+    xch = {}
+    if gather_on:
+        for cx in ctxs:
+            xch[id(cx)] = dict(pin=torch.zeros((nf_max, hd.RECORD_F64), dtype=torch.float64).pin_memory(),
+                               dev=torch.zeros((nf_max, hd.RECORD_F64), dtype=torch.float64, device="cuda"),
+                               out=torch.zeros((world, nf_max, hd.RECORD_F64), dtype=torch.float64, device="cuda"),
+                               ev=torch.cuda.Event())
     state = {}
 
     best_bufs = {id(cx): np.zeros(nf, dtype=native.RECT_DTYPE) for cx in ctxs}
@@ -230,10 +240,14 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
         # (one C-ABI call, ht_detect_collect_best: the Python host was the limiter of a 0.3 ms step with three calls and copies)
         best, nhits = cx.detect_collect_best(1, best_bufs[id(cx)])
         state["nhits"], state["best"] = nhits, best
-        if world > 1:  # the path's one exchange step: every rank ends up with every frame's best-face rectangle
+        if gather_on:  # the path's one exchange step: every rank ends up with every frame's best-face rectangle
+            x = xch[id(cx)]
+            x["ev"].synchronize()  # the previous use of this set (depth steps ago) has been copied to the device
             rec = hd.pack_best_records(best, f0, nf_max)
-            rec_local.copy_(torch.from_numpy(rec), non_blocking=False)
-            state["gathered"] = hd.allgather_records(rec_local, world, nf_max)
+            x["pin"].numpy()[:] = rec
+            x["dev"].copy_(x["pin"], non_blocking=True)
+            x["ev"].record()
+            state["gathered"] = hd.allgather_records(x["dev"], world, nf_max, out=x["out"])
             state["rec"] = rec
         return best
 
@@ -263,10 +277,13 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     fps = total * steps / dt
 
     gather_ok = None
-    if world > 1:  # outside the timed region: the gathered tensor must be the concatenation of every rank's own records
+    if gather_on:  # outside the timed region: the gathered tensor must be the concatenation of every rank's own records
         mine = state["rec"]
         everyone = [None] * world
-        dist.all_gather_object(everyone, mine)
+        if world > 1:
+            dist.all_gather_object(everyone, mine)
+        else:
+            everyone = [mine]
         if rank == 0:
             got = state["gathered"].cpu().numpy()
             gather_ok = all(np.array_equal(got[r], everyone[r]) for r in range(world))

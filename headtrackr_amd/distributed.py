@@ -63,14 +63,17 @@ def pack_best_records(best: np.ndarray, first_frame: int, rows: int | None = Non
     return rec
 
 
-def allgather_records(rec_local, world: int, max_frames_per_rank: int):
+def allgather_records(rec_local, world: int, max_frames_per_rank: int, out=None):
     """All-gathers one [max_frames_per_rank, 8] float64 tensor per rank into [world, max_frames_per_rank, 8].
-    rec_local must already be padded to max_frames_per_rank rows and live on the device the backend expects."""
+    rec_local must already be padded to max_frames_per_rank rows and live on the device the backend expects.
+    out: optional preallocated result tensor (a steady-state caller reuses one per batch in flight)."""
     import torch
     import torch.distributed as dist
 
     assert rec_local.shape == (max_frames_per_rank, RECORD_F64) and rec_local.dtype == torch.float64
-    out = torch.empty((world, max_frames_per_rank, RECORD_F64), dtype=torch.float64, device=rec_local.device)
+    if out is None:
+        out = torch.empty((world, max_frames_per_rank, RECORD_F64), dtype=torch.float64, device=rec_local.device)
+    assert out.shape == (world, max_frames_per_rank, RECORD_F64) and out.dtype == torch.float64
     if world == 1:
         out[0].copy_(rec_local)
         return out

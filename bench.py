@@ -59,6 +59,7 @@ def parse():
                     "0 = auto: 3 while one batch (frames + pyramid) fits the 256 MB Infinity Cache, else 2 (measured: 320x240 x 256 best at 3, 1280x720 x 128 at 2)")
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steady-state work before the warm-up steps (0 for profiler runs)")
     ap.add_argument("--no-sub", action="store_true", help="only the primary workload (no c4 / c3 sub-records)")
+    ap.add_argument("--no-requeue", action="store_true", help="A/B: enqueue a context's next batch only after its results were post-processed")
     a = ap.parse_args()
     if a.steps <= 0:
         a.steps = DEFAULT_STEPS[a.workload]
@@ -235,10 +236,15 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
 
     best_bufs = {id(cx): np.zeros(nf, dtype=native.RECT_DTYPE) for cx in ctxs}
 
-    def finish(cx):
+    def finish(cx, requeue=False):
         # raw hits -> sorted -> seq rects -> ccv's grouping -> facetrackr's best face per frame: all inside the timed step
-        # (one C-ABI call, ht_detect_collect_best: the Python host was the limiter of a 0.3 ms step with three calls and copies)
-        best, nhits = cx.detect_collect_best(1, best_bufs[id(cx)])
+        # (one C-ABI call, ht_detect_collect_best: the Python host was the limiter of a 0.3 ms step with three calls and copies).
+        # requeue: the context's next batch is enqueued inside that call, right after the raw hits reached the host and before they
+        # are sorted and grouped — `depth` batches stay in flight while the host post-processes
+        if requeue:
+            best, nhits = cx.detect_collect_best_requeue(1, best_bufs[id(cx)], a.flags)
+        else:
+            best, nhits = cx.detect_collect_best(1, best_bufs[id(cx)])
         state["nhits"], state["best"] = nhits, best
         if gather_on:  # the path's one exchange step: every rank ends up with every frame's best-face rectangle
             x = xch[id(cx)]
@@ -252,15 +258,18 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
         return best
 
     def run_steps(k):
-        inflight = []
+        # k batches in all: the first min(depth, k) are enqueued up front, every collected batch re-enqueues its context while
+        # batches remain to be started, the last ones are only collected
+        started = min(depth, k)
+        for i in range(started):
+            ctxs[i].detect_enqueue(a.flags)
         for i in range(k):
-            cx = ctxs[i % depth]
-            if len(inflight) == depth:
-                finish(inflight.pop(0))
-            cx.detect_enqueue(a.flags)
-            inflight.append(cx)
-        while inflight:
-            finish(inflight.pop(0))
+            more = started < k
+            finish(ctxs[i % depth], requeue=more and not a.no_requeue)
+            if more:
+                if a.no_requeue:
+                    ctxs[i % depth].detect_enqueue(a.flags)
+                started += 1
 
     # ~0.2 s of the same work before the W warm-up steps so that clocks, allocator and page tables are in their steady
     # state whatever W the caller chose (a 3-step warm-up is 1 ms of GPU time; a cold first run measured up to 10 % slower)

@@ -128,6 +128,15 @@ class Context:
         self._check(self._lib.ht_detect_collect_best(self._h, min_neighbors, out.ctypes.data, C.byref(total)))
         return out[: self.nframes], total.value
 
+    def detect_collect_best_requeue(self, min_neighbors: int = 1, out: np.ndarray | None = None, next_flags: int = HT_INPUT_RGBA):
+        """detect_collect_best, and the next batch of the bound frames is enqueued as soon as this batch's raw hits are on the host
+        (before they are sorted and grouped)."""
+        if out is None or len(out) < self.nframes:
+            out = np.zeros(max(1, self.nframes), dtype=RECT_DTYPE)
+        total = C.c_uint32(0)
+        self._check(self._lib.ht_detect_collect_best_requeue(self._h, min_neighbors, out.ctypes.data, C.byref(total), next_flags))
+        return out[: self.nframes], total.value
+
     def detect_raw(self, frames: np.ndarray, flags: int = HT_INPUT_RGBA, cap: int = 1 << 16):
         """ccv.grayscale + ccv.detect_objects(..., min_neighbors = 0) for a batch: (hits, per-frame counts)."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)

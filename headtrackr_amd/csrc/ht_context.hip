@@ -829,8 +829,16 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
         std::memcpy(tmp.data(), c->h_pinned + sizeof(HtCounters), (size_t)have * sizeof(ht_hit));
         if (found > have)
             HT_HIP(c, hipMemcpy(tmp.data() + have, c->d_hits + have, (size_t)(found - have) * sizeof(ht_hit), hipMemcpyDeviceToHost));
-        std::sort(tmp.begin(), tmp.end(), hit_less);
     }
+    // every raw hit of this batch is in host memory: the next batch of the same frames buffer may start while the host sorts and
+    // groups this one (ht_detect_collect_best_requeue) — the GPU never runs one batch short during the host's post-processing
+    if (c->requeue_flags >= 0) {
+        const uint32_t fl = (uint32_t)c->requeue_flags;
+        c->requeue_flags = -1;
+        ht_status rq = ht_detect_enqueue(c, fl);
+        if (rq != HT_OK) return rq;
+    }
+    if (found) std::sort(tmp.begin(), tmp.end(), hit_less);
     if (counts)
         for (uint32_t i = 0; i < found; i++)
             if (tmp[i].frame < nfr) counts[tmp[i].frame]++;
@@ -1087,6 +1095,15 @@ extern "C" ht_status ht_detect_collect_best(ht_ctx *c, int32_t min_neighbors, ht
     if (total_hits) *total_hits = total;
     if (st != HT_OK) return st;
     return ht_best_faces(c, c->h_collect_hits.data(), c->h_collect_counts.data(), nfr, min_neighbors, best);
+}
+
+extern "C" ht_status ht_detect_collect_best_requeue(ht_ctx *c, int32_t min_neighbors, ht_rect *best, uint32_t *total_hits, uint32_t next_flags) {
+    if (!c || !best) return HT_ERR_INVALID;
+    if (!c->enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_collect_best_requeue: nothing enqueued");
+    c->requeue_flags = (int64_t)next_flags;
+    const ht_status st = ht_detect_collect_best(c, min_neighbors, best, total_hits);
+    c->requeue_flags = -1;
+    return st;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -275,6 +275,7 @@ struct ht_ctx {
     const uint8_t *d_frames = nullptr;
     size_t frame_stride = 0;
     int nframes = 0;
+    int64_t requeue_flags = -1;   // >= 0: ht_detect_collect enqueues the next batch (these flags) as soon as the raw hits are on the host
     int enq_nframes = 0;  // frames of the batch enqueued last (what ht_detect_collect reports on)
 
     // scan outputs

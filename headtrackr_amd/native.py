@@ -61,7 +61,7 @@ SYMBOLS = [
     "ht_create", "ht_destroy", "ht_last_error", "ht_abi_version", "ht_set_geometry", "ht_num_levels", "ht_plane",
     "ht_windows_per_frame", "ht_pyramid_bytes_per_frame", "ht_upload_frames", "ht_upload_frames_async", "ht_swap_frames", "ht_bind_frames_device", "ht_detect_enqueue",
     "ht_detect_collect", "ht_detect_batch", "ht_pyramid_readback", "ht_stage_counts", "ht_grayscale_batch",
-    "ht_whitebalance_batch", "ht_detect_whitebalance", "ht_hits_to_rects", "ht_group_rects", "ht_best_faces", "ht_detect_collect_best", "ht_camshift_reserve", "ht_camshift_init_batch",
+    "ht_whitebalance_batch", "ht_detect_whitebalance", "ht_hits_to_rects", "ht_group_rects", "ht_best_faces", "ht_detect_collect_best", "ht_detect_collect_best_requeue", "ht_camshift_reserve", "ht_camshift_init_batch",
     "ht_camshift_track_batch", "ht_camshift_track_sequence", "ht_camshift_sequence_collect", "ht_camshift_stats", "ht_camshift_debug_hist", "ht_allgather_records", "ht_allgather_best_faces", "ht_device_count", "ht_profile", "ht_kernel_times", "ht_stream", "ht_synchronize",
 ]
 
@@ -124,6 +124,8 @@ def lib():
     L.ht_best_faces.argtypes = [vp, vp, vp, i32, i32, vp]
     L.ht_detect_collect_best.restype = i32
     L.ht_detect_collect_best.argtypes = [vp, i32, vp, C.POINTER(u32)]
+    L.ht_detect_collect_best_requeue.restype = i32
+    L.ht_detect_collect_best_requeue.argtypes = [vp, i32, vp, vp, C.c_uint32]
     L.ht_camshift_reserve.restype = i32
     L.ht_camshift_reserve.argtypes = [vp, i32]
     L.ht_camshift_init_batch.restype = i32

@@ -180,6 +180,10 @@ ht_status ht_best_faces(const ht_ctx *ctx, const ht_hit *hits, const uint32_t *c
 /* ht_detect_collect + ht_best_faces in one call for batch hosts: waits for the enqueued batch, sorts and groups its raw hits and
  * writes one rect per frame of the batch (facetrackr.js:147-175); the hits stay in the context.  *total_hits = raw hits found. */
 ht_status ht_detect_collect_best(ht_ctx *ctx, int32_t min_neighbors, ht_rect *best, uint32_t *total_hits);
+/* The same, and as soon as the batch's raw hits are in host memory the NEXT batch of the currently bound frames is enqueued with
+ * next_flags (ht_detect_enqueue) — before this batch is sorted and grouped, so the GPU is not one batch short while the host
+ * post-processes.  A streaming host that swaps in new frames first (ht_swap_frames) gets them in that next batch. */
+ht_status ht_detect_collect_best_requeue(ht_ctx *ctx, int32_t min_neighbors, ht_rect *best, uint32_t *total_hits, uint32_t next_flags);
 
 /* ---- camshift: camshift.Tracker (camshift.js:148-354), one tracker per stream ----------------------------- */
 

@@ -233,6 +233,28 @@ def test_early_scan_on_second_stream(cascade, monkeypatch):
         c.close()
 
 
+def test_collect_best_requeue_matches_collect_best(cascade):
+    """ht_detect_collect_best_requeue: same best faces as ht_detect_collect_best, and the next batch is already enqueued"""
+    frames = synth.mixed_batch(24, 320, 240, seed0=4321)
+    c = Context()
+    try:
+        c.set_geometry(320, 240, 24)
+        c.upload(frames)
+        c.detect_enqueue()
+        ref, nref = c.detect_collect_best(1)
+        ref = ref.copy()
+        c.detect_enqueue()
+        for _ in range(3):  # every call collects one batch and starts the next
+            got, n = c.detect_collect_best_requeue(1)
+            assert n == nref and got.tobytes() == ref.tobytes()
+        got, n = c.detect_collect_best(1)  # the batch the last requeue started
+        assert n == nref and got.tobytes() == ref.tobytes()
+        with pytest.raises(Exception):
+            c.detect_collect_best(1)  # nothing enqueued any more
+    finally:
+        c.close()
+
+
 def test_tiny_hit_capacity_reports_overflow(cascade):
     from headtrackr_amd.api import HtError
 

@@ -34,7 +34,9 @@ class Context:
         self._h = h
         self.interval = interval
         self.width = self.height = 0
-        self.nframes = 0
+        self._collected_n = 0
+        self.nframes = 0   # frames currently bound (upload / bind_device / swap_frames)
+        self._enq_n = 0    # frames of the batch enqueued last: what the collect calls report on (ht_ctx.enq_nframes)
 
     # -- plumbing -------------------------------------------------------------------------------------------
     def close(self):
@@ -110,32 +112,43 @@ class Context:
     # -- detect -----------------------------------------------------------------------------------------------
     def detect_enqueue(self, flags: int = HT_INPUT_RGBA):
         self._check(self._lib.ht_detect_enqueue(self._h, flags))
+        self._enq_n = self.nframes
 
+    # The library sizes what it writes (counts[], best[]) by the batch that was ENQUEUED, not by what is bound at collect time
+    # (a streaming host binds or swaps in the next frames in between): the buffers below follow `_enq_n`.
     def detect_collect(self, cap: int = 1 << 16):
+        n = self._collected_n = self._enq_n
         buf = getattr(self, "_hitbuf", None)
         if buf is None or len(buf) < cap:
             buf = self._hitbuf = np.empty(cap, dtype=HIT_DTYPE)  # reused across calls
-        counts = np.empty(max(1, self.nframes), dtype=np.uint32)
+        counts = np.empty(max(1, n), dtype=np.uint32)
         total = C.c_uint32(0)
         self._check(self._lib.ht_detect_collect(self._h, buf.ctypes.data, cap, counts.ctypes.data, C.byref(total)))
-        return buf[: total.value].copy(), counts[: self.nframes]
+        return buf[: total.value].copy(), counts[:n]
 
     def detect_collect_best(self, min_neighbors: int = 1, out: np.ndarray | None = None):
         """ht_detect_collect + ht_best_faces in one C call: (best rect per frame of the enqueued batch, raw hit count)."""
-        if out is None or len(out) < self.nframes:
-            out = np.zeros(max(1, self.nframes), dtype=RECT_DTYPE)
+        n = self._collected_n = self._enq_n
+        if out is None or len(out) < n:
+            out = np.zeros(max(1, n), dtype=RECT_DTYPE)
         total = C.c_uint32(0)
         self._check(self._lib.ht_detect_collect_best(self._h, min_neighbors, out.ctypes.data, C.byref(total)))
-        return out[: self.nframes], total.value
+        return out[:n], total.value
 
     def detect_collect_best_requeue(self, min_neighbors: int = 1, out: np.ndarray | None = None, next_flags: int = HT_INPUT_RGBA):
         """detect_collect_best, and the next batch of the bound frames is enqueued as soon as this batch's raw hits are on the host
         (before they are sorted and grouped)."""
-        if out is None or len(out) < self.nframes:
-            out = np.zeros(max(1, self.nframes), dtype=RECT_DTYPE)
+        n = self._collected_n = self._enq_n
+        if out is None or len(out) < n:
+            out = np.zeros(max(1, n), dtype=RECT_DTYPE)
         total = C.c_uint32(0)
-        self._check(self._lib.ht_detect_collect_best_requeue(self._h, min_neighbors, out.ctypes.data, C.byref(total), next_flags))
-        return out[: self.nframes], total.value
+        self._enq_n = self.nframes  # the batch the library enqueues inside this call covers the frames bound NOW
+        try:
+            self._check(self._lib.ht_detect_collect_best_requeue(self._h, min_neighbors, out.ctypes.data, C.byref(total), next_flags))
+        except HtError:
+            self._enq_n = 0  # a failed collect leaves nothing enqueued that this wrapper could size buffers for
+            raise
+        return out[:n], total.value
 
     def detect_raw(self, frames: np.ndarray, flags: int = HT_INPUT_RGBA, cap: int = 1 << 16):
         """ccv.grayscale + ccv.detect_objects(..., min_neighbors = 0) for a batch: (hits, per-frame counts)."""
@@ -205,9 +218,10 @@ class Context:
         return out
 
     def detect_whitebalance(self, n: int | None = None) -> np.ndarray:
-        """getWhitebalance of the frames of the batch last enqueued with HT_DETECT_WHITEBALANCE (fused into the gray pass)."""
-        n = self.nframes if n is None else n
-        out = np.zeros(n, dtype=np.float64)
+        """getWhitebalance of the frames of the batch COLLECTED last, if it was enqueued with HT_DETECT_WHITEBALANCE (fused into
+        its gray pass; the sums are snapshotted by the collect call, so a batch re-enqueued meanwhile does not disturb them)."""
+        n = self._collected_n if n is None else n
+        out = np.zeros(max(n, 1), dtype=np.float64)[:n]
         self._check(self._lib.ht_detect_whitebalance(self._h, out.ctypes.data, n))
         return out
 
@@ -230,6 +244,13 @@ class Context:
     def camshift_track(self, n: int, calc_angles: bool = True, first: int = 0, fetch: bool = True):
         out = np.zeros(n, dtype=native.CS_TRACKOBJ_DTYPE)
         self._check(self._lib.ht_camshift_track_batch(self._h, first, n, int(calc_angles), out.ctypes.data if fetch else None))
+        return out
+
+    def camshift_track_collect(self, n: int):
+        """Track objects of the last camshift_track(n, fetch=False): waits for it.  Lets a host enqueue the track() of several
+        feeds (contexts) first and collect afterwards."""
+        out = np.zeros(n, dtype=native.CS_TRACKOBJ_DTYPE)
+        self._check(self._lib.ht_camshift_track_collect(self._h, n, out.ctypes.data))
         return out
 
     def camshift_track_sequence(self, dev_ptrs, n: int, calc_angles: bool = True, first: int = 0, frame_stride: int | None = None,
@@ -276,6 +297,11 @@ class Context:
         n = C.c_int32(32)
         self._check(self._lib.ht_kernel_times(self._h, buf.ctypes.data, C.byref(n), int(reset)))
         return {b["name"].decode(): dict(ms=float(b["ms"]), launches=int(b["launches"])) for b in buf[: n.value]}
+
+    @property
+    def graph_launches(self) -> int:
+        """detect_enqueue calls that were served by replaying a captured hipGraph"""
+        return int(self._lib.ht_graph_launches(self._h))
 
     def synchronize(self):
         self._check(self._lib.ht_synchronize(self._h))

@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -627,9 +628,23 @@ __global__ __launch_bounds__(512) void k_cs_lut(const uint32_t *__restrict__ his
     }
 }
 
+// The barrier is a spin on an agent-scope counter, so it is BOUNDED: a workgroup that has waited `budget` shader-clock cycles (a
+// quarter of a second by default, against ~3 us for a healthy barrier) raises the context's error word and stops waiting — at this and
+// every later barrier of the call (s_timeout is sticky).  The host reports HT_ERR_STATE with the next result read-back; the stream's
+// state is then garbage for this call, but nothing hangs.  Co-residency (the premise of the spin) is arranged by the host: one cluster
+// launch in flight per device and process, grid <= one workgroup per CU (launch_track).
+// Ordering: payload stores are sc1 (agent scope) and drained with s_waitcnt vmcnt(0) before the arrival atomic is issued; reads of the
+// payload are sc1 loads issued after the counter was observed.  That is the gfx9 memory model; ht_create refuses any other arch.
+struct ClusterSync {
+    unsigned long long *counter;
+    uint32_t *err;
+    long long budget;
+    int *s_timeout;  // LDS flag of the workgroup
+};
 template <bool SECOND>
 __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img, int W, const double *lut, int x, int y, int w, int h, double (*red)[CL_NT / 64],
-                                               double *s_part, int g, int G, double *__restrict__ parts, unsigned long long *__restrict__ counter, int slot) {
+                                               double *s_part, int g, int G, double *__restrict__ parts, const ClusterSync &sync, int slot) {
+    unsigned long long *const counter = sync.counter;
     constexpr int NW = CL_NT / 64, nv = SECOND ? 6 : 3;
     Mom m = {0, 0, 0, 0, 0, 0};
     const int ww = w - x, hh = h - y;
@@ -684,7 +699,17 @@ __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img,
         if (threadIdx.x == 0) {
             __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long target = (unsigned long long)G * (unsigned long long)(slot + 1);
-            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(2);
+            if (!*sync.s_timeout) {
+                const long long t0 = (long long)__builtin_readcyclecounter();
+                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                    if ((long long)__builtin_readcyclecounter() - t0 > sync.budget) {  // bounded spin: give up, flag it, never wait again
+                        *sync.s_timeout = 1;
+                        atomicOr(sync.err, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
         }
     }
     __syncthreads();
@@ -703,11 +728,13 @@ __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img,
 __global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H, const double *__restrict__ lut_g,
                                                                 HtCsState *__restrict__ states, int first, int calc_angles, int max_it, int G,
                                                                 double *__restrict__ parts, unsigned long long *__restrict__ counters,
-                                                                ht_cs_trackobj *__restrict__ out) {
+                                                                uint32_t *__restrict__ err, long long budget, ht_cs_trackobj *__restrict__ out) {
     __shared__ double lut[4096];
     __shared__ double red[6][CL_NT / 64];
     __shared__ double s_part[CL_MAXG * 6];
     __shared__ int s_sw[4];
+    __shared__ int s_timeout;
+    if (threadIdx.x == 0) s_timeout = 0;
     const int s = blockIdx.x / G, g = blockIdx.x - s * G;
     HtCsState &st = states[first + s];
     const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)s * frame_stride);
@@ -718,15 +745,38 @@ __global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *_
     if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
     __syncthreads();
     double *my_parts = parts + (size_t)s * CL_SLOTS * CL_MAXG * 6;
-    unsigned long long *ctr = counters + s;
+    const ClusterSync sync = {counters + s, err, budget, &s_timeout};
     int slot = 0;
     meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, g == 0, [&](bool second, int x, int y, int w, int h) {
         const int sl = slot++;
-        return second ? cluster_moments<true>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, ctr, sl)
-                      : cluster_moments<false>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, ctr, sl);
+        return second ? cluster_moments<true>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, sync, sl)
+                      : cluster_moments<false>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, sync, sl);
     });
 }
 
+}  // namespace
+
+// One cluster launch (k_cs_meanshift_cluster) in flight per device and process: its workgroups spin on each other, so two such grids
+// from different contexts must not share the chip's workgroup slots (each could hold the slots the other's missing workgroups need).
+// The serialisation is device-side — the launching stream waits for the event recorded after the previous cluster launch on that
+// device — so no host thread blocks.
+namespace {
+struct ClusterGate {
+    std::mutex mu;
+    std::map<int, hipEvent_t> last;  // device -> event recorded after the most recent cluster launch
+};
+ClusterGate &cluster_gate() {
+    static ClusterGate g;
+    return g;
+}
+
+// fetched with every result read-back: a cluster barrier that ran out of its cycle budget surfaces as a status code
+ht_status cs_check_err(ht_ctx *c, const char *where) {
+    if (!c->h_cs_err || *c->h_cs_err == 0) return HT_OK;
+    *c->h_cs_err = 0;
+    (void)hipMemsetAsync(c->d_cs_err, 0, sizeof(uint32_t), c->stream);
+    return ht_fail(c, HT_ERR_STATE, std::string(where) + ": a camshift cluster barrier timed out (workgroups of one stream were not co-resident); the affected streams' state is undefined — re-initialise them");
+}
 }  // namespace
 
 extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
@@ -734,30 +784,49 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
     HT_HIP(c, hipSetDevice(c->device));
     if (c->cs_streams >= nstreams) return HT_OK;
     HT_HIP(c, hipStreamSynchronize(c->stream));
+    // every new buffer first; the context only changes once all of them exist (a failed reservation keeps the old trackers usable)
+    const int ncl = std::min(nstreams, 64);  // the cluster path is only taken for <= 64 streams per call
     HtCsState *ns = nullptr;
-    if (hipMalloc(&ns, sizeof(HtCsState) * (size_t)nstreams) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_reserve: hipMalloc failed");
-    HT_HIP(c, hipMemset(ns, 0, sizeof(HtCsState) * (size_t)nstreams));
-    if (c->d_cs) {  // keep existing trackers
-        HT_HIP(c, hipMemcpy(ns, c->d_cs, sizeof(HtCsState) * (size_t)c->cs_streams, hipMemcpyDeviceToDevice));
-        (void)hipFree(c->d_cs);
+    uint32_t *nhist = nullptr, *nerr = c->d_cs_err, *herr = c->h_cs_err;
+    ht_cs_trackobj *nout = nullptr;
+    double *nlut = nullptr, *nparts = nullptr;
+    unsigned long long *nctr = nullptr;
+    bool ok = hipMalloc(&ns, sizeof(HtCsState) * (size_t)nstreams) == hipSuccess &&
+              hipMalloc(&nhist, sizeof(uint32_t) * 4096 * hist_max_chunks(nstreams) * (size_t)nstreams) == hipSuccess &&
+              hipMalloc(&nout, sizeof(ht_cs_trackobj) * (size_t)nstreams) == hipSuccess &&
+              // cluster mean-shift (few large streams): per stream a LUT, CL_SLOTS x CL_MAXG partial-sum slots and an arrival counter
+              hipMalloc(&nlut, sizeof(double) * 4096 * (size_t)ncl) == hipSuccess &&
+              hipMalloc(&nparts, sizeof(double) * CL_SLOTS * CL_MAXG * 6 * (size_t)ncl) == hipSuccess &&
+              hipMalloc(&nctr, sizeof(unsigned long long) * (size_t)ncl) == hipSuccess;
+    if (ok && !nerr) ok = hipMalloc(&nerr, sizeof(uint32_t)) == hipSuccess && hipMemset(nerr, 0, sizeof(uint32_t)) == hipSuccess;
+    if (ok && !herr) {
+        ok = hipHostMalloc(reinterpret_cast<void **>(&herr), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
+        if (ok) *herr = 0;
     }
-    c->d_cs = ns;
+    if (ok) ok = hipMemset(ns, 0, sizeof(HtCsState) * (size_t)nstreams) == hipSuccess;
+    if (ok && c->d_cs)  // keep existing trackers
+        ok = hipMemcpy(ns, c->d_cs, sizeof(HtCsState) * (size_t)c->cs_streams, hipMemcpyDeviceToDevice) == hipSuccess;
+    if (!ok) {
+        (void)hipGetLastError();
+        if (ns) (void)hipFree(ns);
+        if (nhist) (void)hipFree(nhist);
+        if (nout) (void)hipFree(nout);
+        if (nlut) (void)hipFree(nlut);
+        if (nparts) (void)hipFree(nparts);
+        if (nctr) (void)hipFree(nctr);
+        if (nerr && nerr != c->d_cs_err) (void)hipFree(nerr);
+        if (herr && herr != c->h_cs_err) (void)hipHostFree(herr);
+        return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_reserve: allocation failed (the previous reservation is unchanged)");
+    }
+    if (c->d_cs) (void)hipFree(c->d_cs);
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
-    c->d_cs_hist = nullptr;
-    c->d_cs_out = nullptr;
-    HT_HIP(c, hipMalloc(&c->d_cs_hist, sizeof(uint32_t) * 4096 * hist_max_chunks(nstreams) * (size_t)nstreams));
-    HT_HIP(c, hipMalloc(&c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)nstreams));
-    // cluster mean-shift (few large streams): per stream a LUT, CL_SLOTS x CL_MAXG partial-sum slots and an arrival counter
     if (c->d_cs_lut) (void)hipFree(c->d_cs_lut);
     if (c->d_cs_parts) (void)hipFree(c->d_cs_parts);
     if (c->d_cs_ctr) (void)hipFree(c->d_cs_ctr);
-    c->d_cs_lut = c->d_cs_parts = nullptr;
-    c->d_cs_ctr = nullptr;
-    const int ncl = std::min(nstreams, 64);  // the cluster path is only taken for <= 64 streams per call
-    HT_HIP(c, hipMalloc(&c->d_cs_lut, sizeof(double) * 4096 * (size_t)ncl));
-    HT_HIP(c, hipMalloc(&c->d_cs_parts, sizeof(double) * CL_SLOTS * CL_MAXG * 6 * (size_t)ncl));
-    HT_HIP(c, hipMalloc(&c->d_cs_ctr, sizeof(unsigned long long) * (size_t)ncl));
+    c->d_cs = ns, c->d_cs_hist = nhist, c->d_cs_out = nout, c->d_cs_lut = nlut, c->d_cs_parts = nparts, c->d_cs_ctr = nctr;
+    c->d_cs_err = nerr, c->h_cs_err = herr;
+    c->cs_last_n = c->cs_last_chunks = 0;  // the debug histogram buffer is new
     c->cs_streams = nstreams;
     return HT_OK;
 }
@@ -768,6 +837,7 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
     if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_init_batch: stream range not reserved");
     HT_HIP(c, hipSetDevice(c->device));
     ht_cs_rect *d_rects = reinterpret_cast<ht_cs_rect *>(c->d_cs_out);  // scratch: sizeof(ht_cs_trackobj) >= sizeof(ht_cs_rect)
+    c->cs_track_pending_n = 0;  // ... which overwrites the results of an uncollected enqueue-only track call
     HT_HIP(c, hipMemcpyAsync(d_rects, rects, sizeof(ht_cs_rect) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     {
         HtProfScope ps(c, "cs_init");
@@ -807,7 +877,9 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
         HT_HIP(c, hipGetLastError());
     }
     // a few large frames: G workgroups per stream share every moment pass (k_cs_meanshift_cluster); otherwise one workgroup per stream
-    const int G = std::min(CL_MAXG, 256 / std::max(n, 1));
+    // cluster size: the grid never exceeds one workgroup per CU of THIS device, so it is co-resident whatever else is resident
+    // (a CU has room for four of these workgroups); fewer than 4 workgroups per stream are not worth the barriers
+    const int G = std::min(CL_MAXG, c->num_cus / std::max(n, 1));
     if (c->cs_cluster && n <= 64 && G >= 4 && npix >= c->cs_cluster_min_px && c->dbg_cs_iters > 0) {
         {
             HtProfScope ps(c, "cs_lut");
@@ -816,9 +888,15 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
             HT_HIP(c, hipGetLastError());
         }
         HtProfScope ps(c, "cs_meanshift");
+        ClusterGate &gate = cluster_gate();
+        std::lock_guard<std::mutex> lk(gate.mu);
+        hipEvent_t &ev = gate.last[c->device];
+        if (!ev) HT_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        else HT_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));  // the previous cluster grid on this device (any context) has drained
         hipLaunchKernelGGL(k_cs_meanshift_cluster, dim3(n * G), dim3(CL_NT), 0, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_lut, c->d_cs, first,
-                           calc_angles, c->dbg_cs_iters, G, c->d_cs_parts, c->d_cs_ctr, d_out);
+                           calc_angles, c->dbg_cs_iters, G, c->d_cs_parts, c->d_cs_ctr, c->d_cs_err, (long long)c->cs_barrier_budget, d_out);
         HT_HIP(c, hipGetLastError());
+        HT_HIP(c, hipEventRecord(ev, c->stream));
     } else {
         HtProfScope ps(c, "cs_meanshift");
         hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), (size_t)CS_REGION_CAP * 2, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_hist, (int)nchunks,
@@ -837,11 +915,25 @@ extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n
     HT_HIP(c, hipSetDevice(c->device));
     ht_status st = launch_track(c, c->d_frames, c->frame_stride, first, n, calc_angles, c->d_cs_out);
     if (st != HT_OK) return st;
+    c->cs_track_pending_n = out ? 0 : n;
     if (out) {
         HT_HIP(c, hipMemcpyAsync(out, c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+        HT_HIP(c, hipMemcpyAsync(c->h_cs_err, c->d_cs_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HT_HIP(c, hipStreamSynchronize(c->stream));
+        return cs_check_err(c, "ht_camshift_track_batch");
     }
     return HT_OK;
+}
+
+extern "C" ht_status ht_camshift_track_collect(ht_ctx *c, int32_t n, ht_cs_trackobj *out) {
+    if (!c || !out || n <= 0) return HT_ERR_INVALID;
+    if (c->cs_track_pending_n != n) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_collect: no enqueue-only ht_camshift_track_batch of n streams is pending");
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipMemcpyAsync(out, c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HT_HIP(c, hipMemcpyAsync(c->h_cs_err, c->d_cs_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    c->cs_track_pending_n = 0;
+    return cs_check_err(c, "ht_camshift_track_collect");
 }
 
 extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_t n, int32_t calc_angles, const void *const *dev_frames,
@@ -890,21 +982,30 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
             if (st != HT_OK) return st;
         }
     }
+    c->cs_seq_pending_n = 0;
     if (out) {
         HT_HIP(c, hipMemcpyAsync(out, c->d_cs_seq_out, need * sizeof(ht_cs_trackobj), hipMemcpyDeviceToHost, c->stream));
+        HT_HIP(c, hipMemcpyAsync(c->h_cs_err, c->d_cs_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
         HT_HIP(c, hipStreamSynchronize(c->stream));
+        return cs_check_err(c, "ht_camshift_track_sequence");
     }
+    c->cs_seq_pending_n = n, c->cs_seq_pending_calls = ncalls, c->cs_seq_pending_all = out_all ? 1 : 0;  // what ht_camshift_sequence_collect may fetch
     return HT_OK;
 }
 
 extern "C" ht_status ht_camshift_sequence_collect(ht_ctx *c, int32_t n, int32_t ncalls, int32_t out_all, ht_cs_trackobj *out) {
     if (!c || !out || n <= 0 || ncalls <= 0) return HT_ERR_INVALID;
     const size_t need = (size_t)n * (size_t)(out_all ? ncalls : 1);
-    if (!c->d_cs_seq_out || c->cs_seq_cap < need) return ht_fail(c, HT_ERR_STATE, "ht_camshift_sequence_collect: no sequence of this size was enqueued");
+    // only the sequence that was enqueued with out == NULL, with the layout it was enqueued with: anything else would read stale or
+    // differently strided track objects
+    if (!c->d_cs_seq_out || c->cs_seq_cap < need || c->cs_seq_pending_n != n || c->cs_seq_pending_calls != ncalls || c->cs_seq_pending_all != (out_all ? 1 : 0))
+        return ht_fail(c, HT_ERR_STATE, "ht_camshift_sequence_collect: no enqueue-only sequence with this n / ncalls / out_all is pending");
     HT_HIP(c, hipSetDevice(c->device));
     HT_HIP(c, hipMemcpyAsync(out, c->d_cs_seq_out, need * sizeof(ht_cs_trackobj), hipMemcpyDeviceToHost, c->stream));
+    HT_HIP(c, hipMemcpyAsync(c->h_cs_err, c->d_cs_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HT_HIP(c, hipStreamSynchronize(c->stream));
-    return HT_OK;
+    c->cs_seq_pending_n = 0;
+    return cs_check_err(c, "ht_camshift_sequence_collect");
 }
 
 extern "C" ht_status ht_camshift_stats(ht_ctx *c, int32_t first, int32_t n, uint64_t *window_pixels, uint64_t *calls, int32_t reset) {

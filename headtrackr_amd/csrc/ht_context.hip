@@ -195,6 +195,7 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     ht_ctx *c = new (std::nothrow) ht_ctx();
     if (!c) return ht_fail(nullptr, HT_ERR_NOMEM, "ht_create: out of host memory");
     c->device = cfg->device;
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     c->interval = cfg->interval;
     c->next = cfg->interval + 1;
     if (cfg->hit_capacity) c->hit_capacity = cfg->hit_capacity;
@@ -255,6 +256,8 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     if (const char *e = getenv("HT_DEBUG_CS_CLUSTER_MINPX")) c->cs_cluster_min_px = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("HT_DEBUG_CS_REGION")) c->cs_region_cap = std::min(40960, std::max(0, atoi(e)));
     if (const char *e = getenv("HT_DEBUG_CS_ITERS")) c->dbg_cs_iters = std::min(10, std::max(0, atoi(e)));
+    if (const char *e = getenv("HT_DEBUG_GRAPH_MAXFRAMES")) c->graph_max_frames = std::max(0, atoi(e));  // 0: never replay graphs (A/B)
+    if (const char *e = getenv("HT_DEBUG_CS_BARRIER_BUDGET")) c->cs_barrier_budget = std::max(1ll, atoll(e));  // test knob: forces barrier time-outs
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
     c->split_stage = std::min<uint32_t>(c->builtin_cascade ? 8u : 4u, c->nstages);
@@ -273,7 +276,9 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     return HT_OK;
 }
 
+static void destroy_graphs(ht_ctx *c);
 static void free_geometry(ht_ctx *c) {
+    destroy_graphs(c);  // captured launch sequences hold this geometry's pointers
     if (c->d_levels) (void)hipFree(c->d_levels), c->d_levels = nullptr;
     if (c->d_arena) (void)hipFree(c->d_arena), c->d_arena = nullptr;
     if (c->d_scales) (void)hipFree(c->d_scales), c->d_scales = nullptr;
@@ -316,6 +321,9 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->h_wb_pinned) (void)hipHostFree(c->h_wb_pinned);
+    if (c->d_cs_err) (void)hipFree(c->d_cs_err);
+    if (c->h_cs_err) (void)hipHostFree(c->h_cs_err);
     if (c->d_cs) (void)hipFree(c->d_cs);
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
@@ -630,6 +638,7 @@ extern "C" ht_status ht_set_geometry(ht_ctx *c, int32_t width, int32_t height, i
     free_geometry(c);
     // frames bound / uploaded for the old geometry (incl. a pending ht_upload_frames_async) do not survive a size change
     c->nframes = c->enq_nframes = 0;
+    c->wb_collected_n = -1;
     c->back_n = 0;
     c->d_frames = nullptr;
     c->enqueued = false;
@@ -750,8 +759,10 @@ extern "C" ht_status ht_bind_frames_device(ht_ctx *c, const void *dev_rgba, int3
 // ---------------------------------------------------------------------------------------------------------
 // detect
 
-static ht_status wb_scratch(ht_ctx *c) {  // 4 u64 per frame: R, G, B channel sums (+ pad)
-    const size_t need = sizeof(unsigned long long) * 4 * (size_t)std::max(c->max_batch, 1);
+// 4 u64 per frame (R, G, B channel sums + pad), two regions of max_batch frames: the batch in flight (fused into its gray pass) and the
+// stand-alone ht_whitebalance_batch; plus the pinned staging the in-flight batch's sums are copied to by ht_detect_collect
+static ht_status wb_scratch(ht_ctx *c) {
+    const size_t region = sizeof(unsigned long long) * 4 * (size_t)std::max(c->max_batch, 1), need = 2 * region;
     if (c->d_scratch_bytes < need) {
         HT_HIP(c, hipStreamSynchronize(c->stream));
         if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -760,32 +771,107 @@ static ht_status wb_scratch(ht_ctx *c) {  // 4 u64 per frame: R, G, B channel su
         if (hipMalloc(&c->d_scratch, need) != hipSuccess) return ht_fail(c, HT_ERR_NOMEM, "whitebalance scratch: hipMalloc failed");
         c->d_scratch_bytes = need;
     }
+    if (c->h_wb_pinned_bytes < region) {
+        HT_HIP(c, hipStreamSynchronize(c->stream));
+        if (c->h_wb_pinned) (void)hipHostFree(c->h_wb_pinned);
+        c->h_wb_pinned = nullptr;
+        c->h_wb_pinned_bytes = 0;
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_wb_pinned), region, hipHostMallocDefault) != hipSuccess)
+            return ht_fail(c, HT_ERR_NOMEM, "whitebalance staging: hipHostMalloc failed");
+        c->h_wb_pinned_bytes = region;
+    }
     return HT_OK;
 }
+static unsigned long long *wb_standalone_region(ht_ctx *c) {
+    return reinterpret_cast<unsigned long long *>(c->d_scratch) + 4 * (size_t)std::max(c->max_batch, 1);
+}
+
+// the stream work of one detect batch: counters, (whitebalance sums,) gray, pyramid generations, cascade scan
+static ht_status detect_enqueue_body(ht_ctx *c, uint32_t flags) {
+    HT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(HtCounters), c->stream));
+    c->early_launched = false;
+    if (flags & HT_SCAN_STATS) HT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS, c->stream));
+    ht_status st;
+    c->wb_fused = false;
+    const bool wb = (flags & HT_DETECT_WHITEBALANCE) != 0;
+    if (wb) {  // channel sums ride along with the gray pass (no second read of the frames)
+        HT_HIP(c, hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned long long) * 4 * (size_t)c->nframes, c->stream));
+        c->wb_fused = (c->W & 3) == 0;  // the linear gray kernel carries the sums; odd widths take the separate pass below
+    }
+    st = ht_launch_pyramid(c, flags);
+    c->wb_fused = false;
+    if (st != HT_OK) return st;
+    if (wb && (c->W & 3) != 0 && (st = ht_launch_whitebalance(c, c->d_scratch, false)) != HT_OK) return st;
+    return ht_launch_scan(c, flags);
+}
+
+static void destroy_graphs(ht_ctx *c) {
+    for (auto &g : c->graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.graph) (void)hipGraphDestroy(g.graph);
+    }
+    c->graphs.clear();
+}
+
+extern "C" uint64_t ht_graph_launches(const ht_ctx *c) { return c ? c->graph_launches : 0; }
 
 extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
     if (!c) return HT_ERR_INVALID;
     if (!c->d_frames || c->nframes <= 0) return ht_fail(c, HT_ERR_STATE, "ht_detect_enqueue: no frames bound");
     HT_HIP(c, hipSetDevice(c->device));
-    HT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(HtCounters), c->stream));
-    c->early_launched = false;
-    c->stats_enqueued = (flags & HT_SCAN_STATS) != 0;
-    if (c->stats_enqueued) HT_HIP(c, hipMemsetAsync(c->d_stats, 0, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS, c->stream));
     ht_status st;
-    c->wb_fused = false;
-    c->wb_enqueued = false;
-    if (flags & HT_DETECT_WHITEBALANCE) {  // channel sums ride along with the gray pass (no second read of the frames)
-        if ((st = wb_scratch(c)) != HT_OK) return st;
-        HT_HIP(c, hipMemsetAsync(c->d_scratch, 0, sizeof(unsigned long long) * 4 * (size_t)c->nframes, c->stream));
-        c->wb_fused = (c->W & 3) == 0;  // the linear gray kernel carries the sums; odd widths take the separate pass below
-        c->wb_enqueued = true;
+    if ((flags & HT_DETECT_WHITEBALANCE) && (st = wb_scratch(c)) != HT_OK) return st;  // may allocate and synchronise: never inside a capture
+    // Small batches are launch-bound (one 1080p frame: ~0.13 ms of kernels inside a ~0.38 ms sequence of ~10 dependent launches):
+    // the second enqueue of the same (frames, count, flags) captures the sequence into a hipGraph, later ones replay it.  The first
+    // one always runs plainly (it also sets the function attributes a capture must not).
+    const bool graph_ok = c->graph_max_frames > 0 && c->nframes <= c->graph_max_frames && c->own_stream && !c->profiling && !c->early_scan &&
+                          !(flags & HT_SCAN_STATS);
+    bool done = false;
+    if (graph_ok) {
+        HtDetectGraph *g = nullptr;
+        for (auto &e : c->graphs)
+            if (e.frames == c->d_frames && e.frame_stride == c->frame_stride && e.nframes == c->nframes && e.flags == flags) g = &e;
+        if (!g) {
+            if (c->graphs.size() >= 8) {  // a streaming host alternates between two frame buffers; 8 keys are plenty
+                HtDetectGraph &old = c->graphs.front();
+                if (old.exec) (void)hipGraphExecDestroy(old.exec);
+                if (old.graph) (void)hipGraphDestroy(old.graph);
+                c->graphs.erase(c->graphs.begin());
+            }
+            c->graphs.emplace_back();
+            g = &c->graphs.back();
+            g->frames = c->d_frames, g->frame_stride = c->frame_stride, g->nframes = c->nframes, g->flags = flags;
+        }
+        if (!g->exec && g->seen == 1) {
+            if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                st = detect_enqueue_body(c, flags);
+                hipGraph_t graph = nullptr;
+                const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                if (st == HT_OK && e == hipSuccess && graph && hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                    g->graph = graph;
+                } else {  // not capturable here: keep launching plainly
+                    if (graph) (void)hipGraphDestroy(graph);
+                    g->exec = nullptr;
+                    g->seen = 1 << 30;
+                    (void)hipGetLastError();
+                }
+            } else {
+                (void)hipGetLastError();
+                g->seen = 1 << 30;
+            }
+        }
+        if (g->exec) {
+            HT_HIP(c, hipGraphLaunch(g->exec, c->stream));
+            c->graph_launches++;
+            c->early_launched = false;
+            done = true;
+        } else if (g->seen < (1 << 30)) {
+            g->seen++;
+        }
     }
-    st = ht_launch_pyramid(c, flags);
-    c->wb_fused = false;
-    if (st != HT_OK) return st;
-    if (c->wb_enqueued && (c->W & 3) != 0 && (st = ht_launch_whitebalance(c, c->d_scratch, false)) != HT_OK) return st;
-    st = ht_launch_scan(c, flags);
-    if (st != HT_OK) return st;
+    if (!done && (st = detect_enqueue_body(c, flags)) != HT_OK) return st;
+    c->stats_enqueued = (flags & HT_SCAN_STATS) != 0;
+    c->wb_enqueued = (flags & HT_DETECT_WHITEBALANCE) != 0;
     c->enqueued = true;
     c->enq_nframes = c->nframes;  // ht_detect_collect reports THIS batch even if other frames were bound / swapped in meanwhile
     return HT_OK;
@@ -807,9 +893,20 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
     const uint32_t spec = std::min<uint32_t>(HT_PINNED_HITS, c->hit_capacity);
     HT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_counters, sizeof(HtCounters), hipMemcpyDeviceToHost, c->stream));
     HT_HIP(c, hipMemcpyAsync(c->h_pinned + sizeof(HtCounters), c->d_hits, (size_t)spec * sizeof(ht_hit), hipMemcpyDeviceToHost, c->stream));
+    // the whitebalance sums of THIS batch travel with its counters: a re-enqueue below (or any later enqueue) zeroes and refills the
+    // device sums, ht_detect_whitebalance reports the snapshot of the batch collected last
+    const bool wb_snap = c->wb_enqueued && c->h_wb_pinned;
+    if (wb_snap)
+        HT_HIP(c, hipMemcpyAsync(c->h_wb_pinned, c->d_scratch, sizeof(unsigned long long) * 4 * (size_t)c->enq_nframes, hipMemcpyDeviceToHost, c->stream));
     HT_HIP(c, hipStreamSynchronize(c->stream));
     std::memcpy(&c->h_counters, c->h_pinned, sizeof(HtCounters));
     c->enqueued = false;
+    if (wb_snap) {
+        c->h_wb_sums.assign(c->h_wb_pinned, c->h_wb_pinned + 4 * (size_t)c->enq_nframes);
+        c->wb_collected_n = c->enq_nframes;
+    } else {
+        c->wb_collected_n = -1;
+    }
     std::memset(c->h_stage_in, 0, sizeof(c->h_stage_in));
     if (c->stats_enqueued) {
         std::vector<unsigned long long> sh((size_t)64 * HT_STAT_SHARDS);
@@ -901,18 +998,14 @@ extern "C" ht_status ht_grayscale_batch(ht_ctx *c, uint8_t *host_rgba, int32_t n
     return st;
 }
 
-// per-frame channel sums on the device -> getWhitebalance values (whitebalance.js:14-26)
-static ht_status wb_finish(ht_ctx *c, double *out, int32_t n) {
-    std::vector<unsigned long long> sums((size_t)n * 4);
-    HT_HIP(c, hipMemcpyAsync(sums.data(), c->d_scratch, sizeof(unsigned long long) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HT_HIP(c, hipStreamSynchronize(c->stream));
+// per-frame channel sums -> getWhitebalance values (whitebalance.js:14-26)
+static void wb_values(const ht_ctx *c, const unsigned long long *sums, double *out, int32_t n) {
     const double imagesize = (double)c->W * (double)c->H;  // whitebalance.js:14
     for (int i = 0; i < n; i++) {
         // r, g, b are sums of integers < 2^53: exactly what the reference's double accumulation holds (whitebalance.js:17-21)
         const double avgr = (double)sums[4 * i] / imagesize, avgg = (double)sums[4 * i + 1] / imagesize, avgb = (double)sums[4 * i + 2] / imagesize;
         out[i] = (avgr + avgg + avgb) / 3;  // whitebalance.js:23-26
     }
-    return HT_OK;
 }
 
 extern "C" ht_status ht_whitebalance_batch(ht_ctx *c, double *out, int32_t n) {
@@ -921,17 +1014,22 @@ extern "C" ht_status ht_whitebalance_batch(ht_ctx *c, double *out, int32_t n) {
     HT_HIP(c, hipSetDevice(c->device));
     ht_status st = wb_scratch(c);
     if (st != HT_OK) return st;
-    if ((st = ht_launch_whitebalance(c, c->d_scratch, true)) != HT_OK) return st;
-    c->wb_enqueued = false;  // the scratch sums now belong to this call
-    return wb_finish(c, out, n);
+    unsigned long long *d_sums = wb_standalone_region(c);  // never the region a batch in flight accumulates into
+    if ((st = ht_launch_whitebalance(c, reinterpret_cast<double *>(d_sums), true)) != HT_OK) return st;
+    std::vector<unsigned long long> sums((size_t)n * 4);
+    HT_HIP(c, hipMemcpyAsync(sums.data(), d_sums, sizeof(unsigned long long) * 4 * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    wb_values(c, sums.data(), out, n);
+    return HT_OK;
 }
 
 extern "C" ht_status ht_detect_whitebalance(ht_ctx *c, double *out, int32_t n) {
     if (!c || !out) return HT_ERR_INVALID;
-    if (!c->wb_enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_whitebalance: the last ht_detect_enqueue did not carry HT_DETECT_WHITEBALANCE");
-    if (n <= 0 || n > c->enq_nframes) return ht_fail(c, HT_ERR_INVALID, "ht_detect_whitebalance: n exceeds the enqueued batch");
-    HT_HIP(c, hipSetDevice(c->device));
-    return wb_finish(c, out, n);
+    if (c->wb_collected_n < 0)
+        return ht_fail(c, HT_ERR_STATE, "ht_detect_whitebalance: the batch collected last was not enqueued with HT_DETECT_WHITEBALANCE (call after ht_detect_collect)");
+    if (n <= 0 || n > c->wb_collected_n) return ht_fail(c, HT_ERR_INVALID, "ht_detect_whitebalance: n exceeds the collected batch");
+    wb_values(c, c->h_wb_sums.data(), out, n);  // host snapshot: no device work, no wait for a batch that was re-enqueued meanwhile
+    return HT_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -193,6 +193,18 @@ struct alignas(16) HtCsState {
     unsigned long long calls;           // measurement: track() calls since the last reset
 };
 
+// A captured detect sequence (memsets + gray + pyramid generations + scan kernels: ~10 dependent launches) replayed with one
+// hipGraphLaunch.  Keyed by everything the kernels' arguments depend on besides the geometry (which owns the cache).
+struct HtDetectGraph {
+    const uint8_t *frames = nullptr;
+    size_t frame_stride = 0;
+    int nframes = 0;
+    uint32_t flags = 0;
+    int seen = 0;                  // plain enqueues of this key so far (the sequence is captured on the second one)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
 // ---------------------------------------------------------------------------------------------------------
 struct HtKernelTimer {
     std::string name;
@@ -275,6 +287,11 @@ struct ht_ctx {
     const uint8_t *d_frames = nullptr;
     size_t frame_stride = 0;
     int nframes = 0;
+    // small batches (a live feed = 1 frame) are launch-bound: ~10 dependent launches cost more than their kernels.  Their sequence is
+    // captured into a hipGraph per (frames pointer, count, flags) and replayed.  0 disables (HT_DEBUG_GRAPH_MAXFRAMES)
+    int graph_max_frames = 16;
+    std::vector<HtDetectGraph> graphs;
+    uint64_t graph_launches = 0;  // measurement: enqueues served by a graph replay
     int64_t requeue_flags = -1;   // >= 0: ht_detect_collect enqueues the next batch (these flags) as soon as the raw hits are on the host
     int enq_nframes = 0;  // frames of the batch enqueued last (what ht_detect_collect reports on)
 
@@ -296,7 +313,13 @@ struct ht_ctx {
     double *d_scratch = nullptr;
     size_t d_scratch_bytes = 0;
     bool wb_fused = false;     // set around ht_launch_pyramid: the gray kernel also accumulates the channel sums into d_scratch
-    bool wb_enqueued = false;  // the last ht_detect_enqueue carried HT_DETECT_WHITEBALANCE (ht_detect_whitebalance may be called)
+    bool wb_enqueued = false;  // the batch enqueued last carried HT_DETECT_WHITEBALANCE: ht_detect_collect snapshots its sums
+    // d_scratch holds two regions of 4 u64 per frame: [0, max_batch) the sums of the batch in flight (fused gray pass),
+    // [max_batch, 2 max_batch) the stand-alone ht_whitebalance_batch — so neither can zero the other's sums
+    unsigned long long *h_wb_pinned = nullptr;       // pinned staging of the in-flight batch's sums (copied with the counters)
+    size_t h_wb_pinned_bytes = 0;
+    std::vector<unsigned long long> h_wb_sums;       // channel sums of the batch COLLECTED last (what ht_detect_whitebalance reports)
+    int wb_collected_n = -1;                         // frames in h_wb_sums; -1: the collected batch carried no HT_DETECT_WHITEBALANCE
 
     // camshift
     int cs_streams = 0;
@@ -309,6 +332,13 @@ struct ht_ctx {
     uint32_t cs_cluster_min_px = 400000;                 // frames at least this large take it (HT_DEBUG_CS_CLUSTER_MINPX)
     ht_cs_trackobj *d_cs_seq_out = nullptr;  // ht_camshift_track_sequence: [calls][streams] results, one D2H at the end
     size_t cs_seq_cap = 0;
+    // the sequence enqueued with out == NULL that ht_camshift_sequence_collect may fetch (n == 0: none pending)
+    int cs_seq_pending_n = 0, cs_seq_pending_calls = 0, cs_seq_pending_all = 0;
+    int cs_track_pending_n = 0;        // streams of the ht_camshift_track_batch enqueued with out == NULL (ht_camshift_track_collect)
+    uint32_t *d_cs_err = nullptr;      // device word: a cluster barrier ran out of its cycle budget (k_cs_meanshift_cluster)
+    uint32_t *h_cs_err = nullptr;      // pinned copy, fetched with every result read-back
+    long long cs_barrier_budget = 1ll << 28;  // shader-clock cycles a workgroup waits at one cluster barrier (HT_DEBUG_CS_BARRIER_BUDGET)
+    int num_cus = 256;                 // hipDeviceProp_t::multiProcessorCount: sizes the cluster of k_cs_meanshift_cluster
     int cs_fused_min_streams = 192;  // >= this many streams per call: k_cs_track_fused (HT_DEBUG_CS_FUSED_MIN)
     bool cs_seq_attr_set = false;
     bool cs_seq_fused = true;      // HT_DEBUG_CS_SEQ_FUSED=0: ht_camshift_track_sequence launches one kernel per call (A/B)

@@ -62,7 +62,7 @@ SYMBOLS = [
     "ht_windows_per_frame", "ht_pyramid_bytes_per_frame", "ht_upload_frames", "ht_upload_frames_async", "ht_swap_frames", "ht_bind_frames_device", "ht_detect_enqueue",
     "ht_detect_collect", "ht_detect_batch", "ht_pyramid_readback", "ht_stage_counts", "ht_grayscale_batch",
     "ht_whitebalance_batch", "ht_detect_whitebalance", "ht_hits_to_rects", "ht_group_rects", "ht_best_faces", "ht_detect_collect_best", "ht_detect_collect_best_requeue", "ht_camshift_reserve", "ht_camshift_init_batch",
-    "ht_camshift_track_batch", "ht_camshift_track_sequence", "ht_camshift_sequence_collect", "ht_camshift_stats", "ht_camshift_debug_hist", "ht_allgather_records", "ht_allgather_best_faces", "ht_device_count", "ht_profile", "ht_kernel_times", "ht_stream", "ht_synchronize",
+    "ht_camshift_track_batch", "ht_camshift_track_collect", "ht_camshift_track_sequence", "ht_camshift_sequence_collect", "ht_camshift_stats", "ht_camshift_debug_hist", "ht_allgather_records", "ht_allgather_best_faces", "ht_device_count", "ht_profile", "ht_kernel_times", "ht_stream", "ht_graph_launches", "ht_synchronize",
 ]
 
 _lib = None
@@ -154,6 +154,10 @@ def lib():
     L.ht_kernel_times.argtypes = [vp, vp, C.POINTER(i32), i32]
     L.ht_stream.restype = vp
     L.ht_stream.argtypes = [vp]
+    L.ht_camshift_track_collect.restype = i32
+    L.ht_camshift_track_collect.argtypes = [vp, i32, vp]
+    L.ht_graph_launches.restype = C.c_uint64
+    L.ht_graph_launches.argtypes = [vp]
     L.ht_synchronize.restype = i32
     L.ht_synchronize.argtypes = [vp]
     _lib = L

@@ -193,6 +193,10 @@ ht_status ht_camshift_reserve(ht_ctx *ctx, int32_t nstreams);
 ht_status ht_camshift_init_batch(ht_ctx *ctx, int32_t first, int32_t n, const ht_cs_rect *rects);
 /* track (camshift.js:213-312) for streams [first, first+n) on bound frames [0, n); out[n] (may be NULL: enqueue only). */
 ht_status ht_camshift_track_batch(ht_ctx *ctx, int32_t first, int32_t n, int32_t calc_angles, ht_cs_trackobj *out);
+/* Results of the last ht_camshift_track_batch that was enqueued with out == NULL (same n): waits for it and copies the track objects.
+ * A host that serves several feeds on several contexts enqueues every feed's track() first and collects afterwards, so the feeds'
+ * kernels overlap on the GPU (the reference's loop, main.js:168-180, is one feed; this is its K-feed form). */
+ht_status ht_camshift_track_collect(ht_ctx *ctx, int32_t n, ht_cs_trackobj *out);
 /* ncalls successive track() calls (camshift.js:213-220 called once per video frame, main.js:168-180) for streams
  * [first, first+n) in ONE host call: call k uses the n device-resident frames at dev_frames[k] (frame_stride bytes apart;
  * same geometry as ht_set_geometry).  A stream's calls are sequentially dependent (its search window), so they are
@@ -234,6 +238,9 @@ ht_status ht_profile(ht_ctx *ctx, int32_t on);
 /* Device times accumulated since profiling was switched on (or last reset); *n in: capacity, out: entries. */
 ht_status ht_kernel_times(ht_ctx *ctx, ht_kernel_time *out, int32_t *n, int32_t reset);
 void *ht_stream(const ht_ctx *ctx); /* the hipStream_t the ctx enqueues on */
+/* ht_detect_enqueue calls served by replaying a captured hipGraph (batches of <= 16 frames: the ~10 dependent launches of a detect
+ * sequence are captured once per (frames pointer, count, flags) and replayed with one hipGraphLaunch). */
+uint64_t ht_graph_launches(const ht_ctx *ctx);
 ht_status ht_synchronize(ht_ctx *ctx);
 
 #ifdef __cplusplus

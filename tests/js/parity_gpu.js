@@ -54,9 +54,13 @@ job.camshift.forEach(function (cs) {
   g.calls.forEach(function (call, i) {
     tracker.track(canvasOf(cs.frames[call.frame], cs.w, cs.h));
     const sw = tracker.getSearchWindow(), to = tracker.getTrackObj();
-    check(near(sw.x, call.sw[0], 1) && near(sw.y, call.sw[1], 1) && near(sw.width, call.sw[2], 5) && near(sw.height, call.sw[3], 5), cs.name + ' call ' + i + ': search window');
+    /* north_star tolerance: +-1 px, +-0.5 deg.  Sizes are multiples of 4 (`<< 2`, camshift.js:240-241) and the window size is
+     * floor(1.1 * size): +-1 px means EQUAL for them */
+    check(near(sw.x, call.sw[0], 1) && near(sw.y, call.sw[1], 1) && sw.width === call.sw[2] && sw.height === call.sw[3], cs.name + ' call ' + i + ': search window');
     check(near(to.x, call.x, 1) && near(to.y, call.y, 1), cs.name + ' call ' + i + ': centre');
-    check(near(to.width, call.width, 4) && near(to.height, call.height, 4), cs.name + ' call ' + i + ': size');
+    check(to.width === call.width && to.height === call.height, cs.name + ' call ' + i + ': size');
+    out.cs_total = (out.cs_total || 0) + 1;
+    if (sw.x === call.sw[0] && sw.y === call.sw[1] && to.x === call.x && to.y === call.y) out.cs_exact = (out.cs_exact || 0) + 1;
     if (call.angle === null) check(Number.isNaN(to.angle), cs.name + ' call ' + i + ': NaN angle');
     else { let d = Math.abs(to.angle - call.angle); d = Math.min(d, Math.abs(d - Math.PI)); check(d <= 0.5 * Math.PI / 180, cs.name + ' call ' + i + ': angle'); }
   });
@@ -82,8 +86,8 @@ job.facetrackr.forEach(function (cs) {
     const t = ft.getTrackingObject();
     check(t.detection === call.detection, cs.name + ' call ' + i + ': detection ' + t.detection + ' vs ' + call.detection);
     check(t.confidence === call.confidence, cs.name + ' call ' + i + ': confidence');
-    const tol = call.detection === 'CS' ? 1 : 0, tols = call.detection === 'CS' ? 4 : 0;
-    check(near(t.x, call.x, tol) && near(t.y, call.y, tol) && near(t.width, call.width, tols) && near(t.height, call.height, tols), cs.name + ' call ' + i + ': rect');
+    const tol = call.detection === 'CS' ? 1 : 0;
+    check(near(t.x, call.x, tol) && near(t.y, call.y, tol) && t.width === call.width && t.height === call.height, cs.name + ' call ' + i + ': rect');
   });
   check(events.length === g.events.length, cs.name + ': facetrackingEvent count ' + events.length + ' vs ' + g.events.length);
   ft.release();
@@ -103,7 +107,7 @@ job.facetrackr.forEach(function (cs) {
     check(JSON.stringify(statuses) === JSON.stringify(call.status), cs.name + ' frame ' + i + ': status ' + JSON.stringify(statuses) + ' vs ' + JSON.stringify(call.status));
     check(r.face.detection === call.detection, cs.name + ' frame ' + i + ': detection');
     const tol = call.detection === 'CS' ? 1.5 : 0; /* smoothed camshift output: +-1 px budget of the track itself */
-    check(near(r.face.x, call.x, tol) && near(r.face.y, call.y, tol) && near(r.face.width, call.width, 4) && near(r.face.height, call.height, 4), cs.name + ' frame ' + i + ': face');
+    check(near(r.face.x, call.x, tol) && near(r.face.y, call.y, tol) && near(r.face.width, call.width, 1e-9) && near(r.face.height, call.height, 1e-9), cs.name + ' frame ' + i + ': face');
     if (call.head === null) check(r.head === null, cs.name + ' frame ' + i + ': no head position expected');
     else check(r.head !== null && near(r.head.x, call.head[0], 0.5) && near(r.head.y, call.head[1], 0.5) && near(r.head.z, call.head[2], 2.5), cs.name + ' frame ' + i + ': head ' + JSON.stringify(r.head) + ' vs ' + JSON.stringify(call.head));
   });
@@ -139,7 +143,7 @@ job.facetrackr.forEach(function (cs) {
       for (let q = 1; q < Math.min(a.length, b.length); q++) {
         if (typeof b[q] === 'string') { check(a[q] === b[q], cs.name + ' frame ' + i + ' stroke ' + k + ': style'); continue; }
         if (b[q] === null) { check(Number.isNaN(a[q]), cs.name + ' frame ' + i + ' stroke ' + k + ': NaN expected'); continue; }
-        const tol = a[0] === 'rotate' ? 0.5 * Math.PI / 180 : (a[0] === 'translate' ? 1 : 4); /* camshift budget: +-1 px, +-0.5 deg, sizes in steps of 4 */
+        const tol = a[0] === 'rotate' ? 0.5 * Math.PI / 180 : (a[0] === 'translate' ? 1 : 0); /* camshift budget: +-1 px, +-0.5 deg; sizes are multiples of 4: equal */
         check(near(a[q], b[q], tol), cs.name + ' frame ' + i + ' stroke ' + k + ' arg ' + q + ': ' + a[q] + ' vs ' + b[q]);
         if (a[0] === 'rotate' ? !near(a[q], b[q], 1e-9) : a[q] !== b[q]) exact = false; /* Math.atan2 vs libm atan2: last-bit differences of the angle */
       }

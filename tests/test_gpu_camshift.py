@@ -1,13 +1,19 @@
 """Parity of the HIP camshift path with the CPU oracle and the reference-JS golden vectors, through the C ABI.
-Integers (search window, centre, size) must match within +-1 px and the angle within +-0.5 deg (BASELINE.json); the
-moment sums are binary64 on both sides but accumulated in a different order, so bit-equality is not promised — in
-practice every case below matches exactly and the test requires >= 95 % exact matches."""
+
+Tolerance = BASELINE.json north_star: (x, y, width, height) within +-1 px, angle within +-0.5 deg.  width / height / search-window
+size are multiples of 4 (`<< 2`, camshift.js:240-241) resp. floor(1.1 * that), so +-1 px means EQUAL for them; the moment sums are
+binary64 on both sides but accumulated in a different (fixed) order, so x / y may in principle differ by one truncation step
+(camshift.js:295-296) — the assertions allow exactly that one pixel and nothing else, every call that is not bit-for-bit the oracle's
+is listed with (test, stream, call), and the module writes exact/total to gpurun_out/camshift_parity.json (also printed with -s)."""
+import atexit
+import json
 import math
+import os
 
 import numpy as np
 import pytest
 
-from conftest import load_golden
+from conftest import ROOT, load_golden
 from headtrackr_amd import synth
 from headtrackr_amd.api import Context
 from oracle import ht_oracle as ho
@@ -16,6 +22,20 @@ pytestmark = pytest.mark.gpu
 CAMSHIFT = load_golden("camshift.json")
 
 ANGLE_TOL = math.radians(0.5)
+PARITY = {"exact": 0, "total": 0, "angle_max_abs_diff_rad": 0.0, "not_exact": []}
+
+
+def _write_parity():
+    if PARITY["total"]:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "camshift_parity.json"), "w") as f:
+            json.dump(PARITY, f, indent=1)
+        print(f"camshift parity: {PARITY['exact']}/{PARITY['total']} track() calls bit-exact in (x, y, width, height, search window); "
+              f"max |angle difference| {PARITY['angle_max_abs_diff_rad']:.3e} rad; not exact: {PARITY['not_exact'][:8]}")
+
+
+atexit.register(_write_parity)
 
 
 @pytest.fixture(scope="module", params=["chunked", "fused"])
@@ -38,27 +58,40 @@ def ctx(request):
     c.close()
 
 
-def check(got, want_sw, want, stats):
+def check(got, want_sw, want, stats, where=None):
+    """one track() call against the oracle / golden vector: sizes exact, positions +-1 px, angle +-0.5 deg; `stats` collects whether
+    the call was bit-exact in every integer-valued output"""
     sw = [int(got["sw_x"]), int(got["sw_y"]), int(got["sw_width"]), int(got["sw_height"])]
     exact = sw == list(want_sw)
     for a, b in zip(sw[:2], want_sw[:2]):
-        assert abs(a - b) <= 1, (sw, want_sw)
-    for a, b in zip(sw[2:], want_sw[2:]):
-        assert abs(a - b) <= 5, (sw, want_sw)  # 1.1 * (size quantised to multiples of 4)
+        assert abs(a - b) <= 1, (where, sw, want_sw)
+    assert sw[2:] == list(want_sw[2:]), (where, sw, want_sw)  # floor(1.1 * size), size a multiple of 4: +-1 px means equal
     for k in ("x", "y"):
-        assert abs(float(got[k]) - want[k]) <= 1, (k, got, want)
+        assert abs(float(got[k]) - want[k]) <= 1, (where, k, got, want)
         exact = exact and float(got[k]) == want[k]
     for k in ("width", "height"):
-        assert abs(float(got[k]) - want[k]) <= 4, (k, got, want)  # `<< 2` quantisation, camshift.js:240-241
-        exact = exact and float(got[k]) == want[k]
+        assert float(got[k]) == want[k], (where, k, got, want)  # multiples of 4 (`<< 2`, camshift.js:240-241): +-1 px means equal
     wa = want["angle"]
     if wa is None or (isinstance(wa, float) and math.isnan(wa)):
         assert math.isnan(float(got["angle"]))
     else:
         d = abs(float(got["angle"]) - wa)
         d = min(d, abs(d - math.pi))  # the angle is defined modulo pi
-        assert d <= ANGLE_TOL, (got, want)
+        assert d <= ANGLE_TOL, (where, got, want)
+        PARITY["angle_max_abs_diff_rad"] = max(PARITY["angle_max_abs_diff_rad"], d)
+    PARITY["total"] += 1
+    PARITY["exact"] += int(exact)
+    if not exact:
+        PARITY["not_exact"].append({"where": str(where), "got": [float(got[k]) for k in ("x", "y", "width", "height")] + sw,
+                                    "want": [want[k] for k in ("x", "y", "width", "height")] + list(want_sw)})
     stats.append(exact)
+
+
+def assert_all_exact(stats, what):
+    """The reduction tree is fixed, so the result is deterministic: on these inputs every call reproduces the oracle bit for bit
+    (measured: a row-major restatement of the oracle's column-major sums differs in 0 of 15 360 calls of the C3 shape)."""
+    bad = len(stats) - sum(stats)
+    assert bad == 0, f"{what}: {bad} of {len(stats)} track() calls within tolerance but not exact: {PARITY['not_exact'][-bad:][:5]}"
 
 
 @pytest.mark.parametrize("case", CAMSHIFT["cases"], ids=lambda c: c["name"])
@@ -73,8 +106,8 @@ def test_golden_sequences(ctx, case):
     for call in case["calls"]:
         ctx.upload(frames[call["frame"]][None])
         got = ctx.camshift_track(1, calc_angles=case["calcAngles"])[0]
-        check(got, call["sw"], call, stats)
-    assert sum(stats) >= 0.95 * len(stats), f"only {sum(stats)}/{len(stats)} calls matched the reference exactly"
+        check(got, call["sw"], call, stats, where=(case["name"], 0, len(stats)))
+    assert_all_exact(stats, case["name"])
 
 
 def test_batch_of_streams_vs_oracle(ctx):
@@ -114,8 +147,8 @@ def test_batch_of_streams_vs_oracle(ctx):
         got = ctx.camshift_track(n, calc_angles=True)
         for s in range(n):
             sw, to = oracles[s].track(seqs[s][k])
-            check(got[s], sw, to, stats)
-    assert sum(stats) >= 0.95 * len(stats), f"only {sum(stats)}/{len(stats)} track() calls matched the oracle exactly"
+            check(got[s], sw, to, stats, where=("batch64", s, k))
+    assert_all_exact(stats, "64 streams x 7 calls")
 
 
 @pytest.mark.parametrize("w,h,n", [(1920, 1080, 1), (641, 363, 3), (61, 45, 2)], ids=["1080p-1stream", "odd-641x363", "tiny-61x45"])
@@ -148,8 +181,8 @@ def test_frame_sizes_and_chunking(w, h, n, fused, monkeypatch):
             got = c.camshift_track(n, calc_angles=True)
             for s in range(n):
                 sw, to = oracles[s].track(seqs[s][k])
-                check(got[s], sw, to, stats)
-        assert sum(stats) >= 0.9 * len(stats), f"only {sum(stats)}/{len(stats)} track() calls matched the oracle exactly"
+                check(got[s], sw, to, stats, where=(f"{w}x{h}", s, k))
+        assert_all_exact(stats, f"{w}x{h}")
     finally:
         c.close()
 
@@ -177,6 +210,88 @@ def test_detect_then_track_like_facetrackr(ctx, golden_facetrackr):
         for k in ("x", "y"):
             assert abs(float(got[k]) - calls[i][k]) <= 1
         for k in ("width", "height"):
-            assert abs(float(got[k]) - calls[i][k]) <= 4
+            assert float(got[k]) == calls[i][k]
         stats.append(all(float(got[k]) == calls[i][k] for k in ("x", "y", "width", "height")))
-    assert sum(stats) >= len(stats) - 1
+    assert sum(stats) == len(stats)
+
+
+def _feeds_1080p(nfeeds, steps):
+    w, h = 1920, 1080
+    feeds, rects = [], []
+    for s in range(nfeeds):
+        cx, cy, a, b = 500 + 150 * s, 400 + 40 * s, 180, 120
+        feeds.append([synth.blob_frame(w, h, cx + 2 * k, cy + k, a, b, (4, 3, 5), (200, 60, 40), seed=300 + 17 * s + k) for k in range(steps)])
+        rects.append((cx - a, cy - b, 2 * a, 2 * b))
+    return feeds, rects
+
+
+def test_six_contexts_track_1080p_feeds_concurrently():
+    """Six contexts (own HIP streams), each tracking one 1920x1080 feed with the CLUSTER mean-shift (32 workgroups per stream that
+    spin on each other at every moment pass).  Every context's whole call sequence is enqueued before any result is fetched, so the
+    six streams have cluster grids pending at the same time (6 x 32 x up to 11 barriers each): cluster launches are serialised per
+    device, the spin is bounded, nothing hangs and every call == the oracle."""
+    from hipmem import DeviceArray
+
+    nctx, steps = 6, 5
+    w, h = 1920, 1080
+    feeds, rects = _feeds_1080p(nctx, steps)
+    ctxs = [Context() for _ in range(nctx)]
+    dev = [[DeviceArray(f) for f in feeds[i]] for i in range(nctx)]
+    try:
+        for i, c in enumerate(ctxs):
+            c.set_geometry(w, h, 1)
+            c.camshift_reserve(1)
+            c.bind_device(dev[i][0].ptr, 1)
+            c.camshift_init([rects[i]])
+        for rounds in range(2):  # twice: the second round starts from the first round's tracker state
+            for i, c in enumerate(ctxs):
+                c.camshift_track_sequence([d.ptr for d in dev[i][1:]], 1, calc_angles=True, fetch="none", keep_all=True)
+        stats = []
+        for i, c in enumerate(ctxs):
+            got = c.camshift_sequence_collect(1, steps - 1, fetch="all")  # the second round's results
+            o = ho.Camshift(True)
+            o.init_tracker(feeds[i][0], rects[i])
+            for rounds in range(2):
+                for k in range(1, steps):
+                    sw, to = o.track(feeds[i][k])
+                    if rounds == 1:
+                        check(got[k - 1, 0], sw, to, stats, where=("6ctx", i, k))
+        assert len(stats) == nctx * (steps - 1)
+        assert_all_exact(stats, "6 contexts x 1080p")
+    finally:
+        for c in ctxs:
+            c.close()
+        for row in dev:
+            for d in row:
+                d.free()
+
+
+def test_cluster_barrier_timeout_is_a_status_code(monkeypatch):
+    """The cluster barrier is a bounded spin: with a budget of one cycle every workgroup that arrives early gives up at once; the
+    call must come back with HT_ERR_STATE (never hang), and the context must work again afterwards."""
+    from headtrackr_amd.api import HtError
+
+    w, h = 1920, 1080
+    feeds, rects = _feeds_1080p(1, 3)
+    monkeypatch.setenv("HT_DEBUG_CS_BARRIER_BUDGET", "1")
+    c = Context()
+    monkeypatch.delenv("HT_DEBUG_CS_BARRIER_BUDGET")
+    good = Context()
+    try:
+        for cx in (c, good):
+            cx.set_geometry(w, h, 1)
+            cx.camshift_reserve(1)
+            cx.upload(feeds[0][0][None])
+            cx.camshift_init([rects[0]])
+            cx.upload(feeds[0][1][None])
+        with pytest.raises(HtError) as e:
+            c.camshift_track(1, calc_angles=True)
+        assert e.value.status == -6 and "barrier" in str(e.value)
+        want = good.camshift_track(1, calc_angles=True)[0]
+        o = ho.Camshift(True)
+        o.init_tracker(feeds[0][0], rects[0])
+        sw, to = o.track(feeds[0][1])
+        check(want, sw, to, [], where=("timeout-good", 0, 0))
+    finally:
+        c.close()
+        good.close()

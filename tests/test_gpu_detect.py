@@ -100,8 +100,10 @@ def _check_pyramid(ctx, w, h):
                 assert got.shape == want.shape and np.array_equal(got, want), f"frame {f} level {i} slot {s}"
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (64, 48), (38, 30), (641, 363)])
+@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (64, 48), (38, 30), (641, 363), (1280, 720), (1920, 1080)])
 def test_pyramid_planes_vs_oracle(ctx, w, h):
+    """all 119 canvases of an N, an S and an F frame, plane by plane; 1920x1080 is the C5 geometry (the binary32-estimate fast path of
+    k_resample and the tile split are size-dependent)"""
     _check_pyramid(ctx, w, h)
 
 
@@ -160,7 +162,7 @@ def test_pyramid_both_tail_kernels(w, h, table, monkeypatch):
         c.close()
 
 
-@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (1280, 720)])
+@pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (1280, 720), (1920, 1080)])
 def test_pyramid_fast_paths_equal_the_declared_binary64_sequence(w, h, monkeypatch):
     """k_resample evaluates a pixel in binary32 and falls back to the declared binary64 sequence next to a rounding boundary;
     exact 2:1 canvases are integer box means.  HT_DEBUG_RS_NOFAST keeps every pixel on the binary64 sequence: all planes of

@@ -41,7 +41,9 @@ def test_odd_sizes(ctx, cascade, w, h):
 
 def test_1080p(ctx, cascade):
     w, h = 1920, 1080
-    frames = np.stack([synth.face_frame(w, h, [(300, 200, 400), (1200, 500, 96), (1700, 100, 64)])])
+    # the C5 geometry: one F, one N and one S frame (raw hits incl. confidence bits; the planes are compared in
+    # test_gpu_detect.py::test_pyramid_planes_vs_oracle[1920-1080])
+    frames = np.stack([synth.face_frame(w, h, [(300, 200, 400), (1200, 500, 96), (1700, 100, 64)]), synth.noise_frame(w, h, 5), synth.smooth_frame(w, h, 6)])
     hits = check(ctx, frames, cascade)
     assert len(hits) >= 20 and ctx.windows_per_frame == 2344044
     p = ctx.plane(38, 0)

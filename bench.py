@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the detect(+camshift) hot path on N MI355X, one JSON line on rank 0.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--scaling weak|strong] [--no-sub]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c4|c5] [--scaling weak|strong] [--feeds K] [--no-sub]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (torch.distributed.run, one
+rank per GPU over RCCL) and fails loudly when fewer than N GPUs are visible; under a launcher WORLD_SIZE must equal --gpus.
 
 A "step" is one pass of the hot path over one batch of synthetic frames that are already resident in HBM:
 gray -> 39-level pyramid -> full BBF cascade scan -> raw hits copied back, sorted, converted to rects, grouped and reduced
@@ -14,10 +17,16 @@ Workloads (BASELINE.json configs):
   c2  256 x 320x240 detect per GPU — the headline `value` (the configuration the metric is quoted on);
   c4  1280x720 detect, 128 frames per GPU (weak) or 1024 frames in total (--scaling strong: 1024 / N per GPU);
   c3  256 streams of 320x240: detect once + initTracker + 60 camshift track() calls per step (ht_camshift_track_sequence);
-  c5  one live 1920x1080 feed per GPU, PCIe every frame.
-The default run (c2) also measures c4 (weak + strong) and c3 with their own bounded budgets and reports them as
-sub-records of the same JSON line ("sub": {"c4_1gpu", "c4_strong", "c3"}), each with its own `roofline` and, at N = 1, the
-unmodified reference JS timed on the host cores as `cpu_baseline`.  --no-sub skips them (profiler runs).
+  c5  --feeds K live 1920x1080 feeds per GPU (own contexts and HIP streams), PCIe every frame, detect every 30th frame.
+The default run (c2) also measures c4 (weak + strong), c3 and c5 (one feed: latency; 8 feeds: the N = 1 point of configs[4]) with
+their own bounded budgets and reports them as sub-records of the same JSON line ("sub": {"c4_1gpu", "c4_strong", "c3", "c5",
+"js_host"}), each with its own `roofline` and, at N = 1, the unmodified reference JS timed on the host cores as `cpu_baseline`.
+--no-sub skips them (profiler runs).
+
+Timing: the K timed steps (barrier + synchronize on both sides, max over ranks) are repeated R times back to back ("rounds"; R is
+chosen so that the timed work is ~0.4 s, K stays what the caller passed) and the MEDIAN block is reported, with the spread
+(`ms_per_step_min` / `ms_per_step_max`): a 20-step block of C2 is 6 ms of GPU time, far too short to quote on its own.
+"dominant kernel" of a roofline = the kernel with the largest device time per step (the sum over its launches).
 """
 import argparse
 import json
@@ -35,7 +44,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 DEFAULT_STEPS = {"c2": 1000, "c4": 300, "c3": 20, "c5": 300}
-SUB_STEPS = {"c4": 100, "c4_strong": 24, "c3": 12}
+SUB_STEPS = {"c4": 100, "c4_strong": 24, "c3": 12, "c5": 90}
 GEOM = {"c2": (320, 240, 256), "c3": (320, 240, 256), "c4": (1280, 720, 128)}
 WORKLOAD_TEXT = {
     "c2": "C2: 256 x 320x240 RGBA frames per GPU, full BBF cascade detect (interval 5) incl. grouping + best face per frame on the host",
@@ -60,6 +69,8 @@ def parse():
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steady-state work before the warm-up steps (0 for profiler runs)")
     ap.add_argument("--no-sub", action="store_true", help="only the primary workload (no c4 / c3 sub-records)")
     ap.add_argument("--no-requeue", action="store_true", help="A/B: enqueue a context's next batch only after its results were post-processed")
+    ap.add_argument("--feeds", type=int, default=1, help="c5: live feeds per GPU (own contexts / HIP streams); 8 on one GPU is the N = 1 point of BASELINE.json configs[4]")
+    ap.add_argument("--rounds", type=int, default=0, help="repetitions of the K-step timed block (median reported); 0 = auto: ~0.4 s of timed work, 3..25 rounds")
     a = ap.parse_args()
     if a.steps <= 0:
         a.steps = DEFAULT_STEPS[a.workload]
@@ -69,20 +80,61 @@ def parse():
 
 
 class Env:
-    def __init__(self, torch, dist, rank, world, local):
-        self.torch, self.dist, self.rank, self.world, self.local = torch, dist, rank, world, local
+    def __init__(self, torch, dist, rank, world, local, stub=False):
+        self.torch, self.dist, self.rank, self.world, self.local, self.stub = torch, dist, rank, world, local, stub
+        self.dev = "cpu" if stub else "cuda"
 
     def fence(self):
         if self.world > 1:
             self.dist.barrier()
-        self.torch.cuda.synchronize()
+        if not self.stub:
+            self.torch.cuda.synchronize()
 
     def max_over_ranks(self, dt):
         if self.world > 1:
-            t = self.torch.tensor([dt], dtype=self.torch.float64, device="cuda")
+            t = self.torch.tensor([dt], dtype=self.torch.float64, device=self.dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
+
+    def timed_rounds(self, run_block, steps, rounds=0, target_s=0.4):
+        """R back-to-back timed blocks of `steps` steps each, every block bracketed by barrier + synchronize on both sides and
+        max-reduced over the ranks.  rounds == 0: R from the first block so that the timed work is ~target_s (3..25; every rank
+        derives the same R from the same max-reduced time).  Returns the list of block times in seconds."""
+        dts = []
+        r = 0
+        while True:
+            self.fence()
+            t0 = time.perf_counter()
+            run_block(steps)
+            self.fence()
+            dts.append(self.max_over_ranks(time.perf_counter() - t0))
+            r += 1
+            if rounds <= 0:
+                rounds = int(min(25, max(3, -(-target_s // max(dts[0], 1e-6)))))
+            if r >= rounds:
+                return dts
+
+
+def round_stats(dts, steps):
+    """median block -> the reported time; min / max -> the spread"""
+    med = float(np.median(dts))
+    return med, dict(rounds=len(dts), ms_per_step=round(med / steps * 1e3, 4), ms_per_step_min=round(min(dts) / steps * 1e3, 4),
+                     ms_per_step_max=round(max(dts) / steps * 1e3, 4))
+
+
+def dominant_roofline(per_step_ms, launches_per_step, bytes_per_step, extra=None):
+    """SURVEY.md §8(d) roofline of the DOMINANT kernel = the one with the largest device time per step (sum of its launches):
+    achieved = algorithmic bytes of a step / that kernel's time per step (for a kernel with one launch per step this is bytes per
+    launch / average launch duration)."""
+    dom = max(per_step_ms, key=per_step_ms.get)
+    ach = bytes_per_step / (per_step_ms[dom] * 1e-3) / 1e9
+    r = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+             kernel_ms_per_step=round(per_step_ms[dom], 5), launches_per_step=round(launches_per_step[dom], 2),
+             avg_launch_ms=round(per_step_ms[dom] / max(launches_per_step[dom], 1e-9), 5), dominant="largest device time per step (sum of its launches)")
+    if extra:
+        r.update(extra)
+    return r
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -278,11 +330,8 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
         while time.perf_counter() - t_pre < prewarm:
             run_steps(8 * depth)
     run_steps(max(warmup, depth))
-    env.fence()
-    t0 = time.perf_counter()
-    run_steps(steps)
-    env.fence()
-    dt = env.max_over_ranks(time.perf_counter() - t0)
+    dts = env.timed_rounds(run_steps, steps, a.rounds)
+    dt, spread = round_stats(dts, steps)
     fps = total * steps / dt
 
     gather_ok = None
@@ -313,21 +362,17 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     kt = ctx.kernel_times(reset=True)
     ctx.profile(False)
     per_step = {k: v["ms"] / psteps for k, v in kt.items()}
-    per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items()}
-    # "dominant kernel" = the longest single launch (the unit the roofline formula is written in).  k_resample runs several
-    # dependent launches per step, each over a different slice of the pyramid; its total per step is in kernel_ms_per_step.
-    dom = max(per_launch, key=per_launch.get)
     P = ctx.pyramid_bytes_per_frame
     b_detect = 4 * W * H + 2 * P  # read RGBA once, write each gray plane once, read it once in the scan
-    launches_per_step = kt[dom]["launches"] / psteps
-    achieved = b_detect * nf / launches_per_step / (per_launch[dom] * 1e-3) / 1e9
     all_traffic = load_traffic(name)
-    roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5),
-                    traffic=all_traffic.get(dom) if (nf, scaling) == (nf_default, "weak") else None,
-                    algorithmic_bytes_per_frame=b_detect, frames_per_launch=nf, avg_launch_ms=round(per_launch[dom], 5))
+    roofline = dominant_roofline(per_step, {k: v["launches"] / psteps for k, v in kt.items()}, b_detect * nf,
+                                 dict(algorithmic_bytes_per_frame=b_detect, frames_per_step=nf))
+    # PMC traffic of the dominant kernel per step (all its launches), from the committed rocprofv3 counter passes
+    tr = all_traffic.get(roofline["kernel"]) if (nf, scaling) == (nf_default, "weak") else None  # profiles/traffic.json: bytes per launch
+    roofline["traffic"] = round(tr * roofline["launches_per_step"]) if tr else None
     dev_ms = sum(per_step.values())
     rec = {
-        "value": round(fps, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "scaling": scaling,
+        "value": round(fps, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, **spread, "scaling": scaling,
         "config": {"workload": WORKLOAD_TEXT[name], "frames_per_gpu": nf, "frames_total": total, "batches_in_flight": depth, "width": W, "height": H,
                    "unique_frames": uniq, "frame_mix": "1/3 LCG noise, 1/3 smooth, 1/3 faces",
                    "parallelism": f"frames block-sharded over {world} GPU(s), all-gather of {nf_max}x64B best-face rect records (verified against the per-rank results)" if world > 1 else "1 GPU"},
@@ -342,8 +387,10 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     rec["kernel_rooflines"] = {k: dict(own_bytes_per_step=own[k], gbs=round(own[k] / (per_step[k] * 1e-3) / 1e9, 1),
                                        frac=round(own[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) for k in own if k in per_step}
     rec["device_ms_per_step"] = round(dev_ms, 5)
+    # whole-path figures (every kernel of a step): device time, and the wall clock of the timed region
     rec["path_hbm_gbs"] = round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2)
     rec["path_hbm_frac"] = round(b_detect * nf / (dev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+    rec["wall_hbm_frac"] = round(b_detect * total / world / (dt / steps) / 1e9 / HBM_PEAK_GBS, 5)
     rec["hits_per_step"] = int(state["nhits"])
     rec["faces_per_step"] = int((state["best"]["neighbors"] > 0).sum())
     if full:
@@ -432,13 +479,14 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
     for i in range(max(warmup, 1)):
         step(i)
     drain()
-    env.fence()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    drain()
-    env.fence()
-    dt = env.max_over_ranks(time.perf_counter() - t0)
+
+    def block(k):
+        for i in range(k):
+            step(i)
+        drain()
+
+    dts = env.timed_rounds(block, steps, a.rounds)
+    dt, spread = round_stats(dts, steps)
     total_frames = world * nf * steps * (CALLS + 1)  # every processed frame: 1 detected + 60 tracked per stream and step
     for cx in ctxs[1:]:
         cx.close()
@@ -458,21 +506,38 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
     b_track = 4 * W * H + 4 * win_px_per_call  # one full-frame histogram pass + the window passes, per stream and call
     # >= 192 streams: ONE kernel per call (k_cs_track_fused: histogram + LUT + mean-shift); fewer: k_cs_hist + k_cs_meanshift
     # (with >= 192 streams ht_camshift_track_sequence puts up to 64 calls of every stream into one launch: times are per CALL below)
-    launches = {k: v["launches"] for k, v in kt.items() if k in ("cs_hist", "cs_meanshift", "cs_track")}
-    per_launch = {k: v["ms"] / CALLS for k, v in kt.items() if k in launches}
-    dom = max(per_launch, key=per_launch.get)
+    launches = {k: v["launches"] for k, v in kt.items() if k in ("cs_hist", "cs_lut", "cs_meanshift", "cs_track")}
+    per_launch = {k: v["ms"] / CALLS for k, v in kt.items() if k in launches}  # device time per track() CALL of the 256 streams
     call_ms = sum(per_launch.values())
-    achieved = b_track * nf / (per_launch[dom] * 1e-3) / 1e9
     own = {"cs_hist": 4 * W * H * nf, "cs_meanshift": 4 * win_px_per_call * nf, "cs_track": b_track * nf}
+    croof = dominant_roofline(per_launch, {k: launches[k] / CALLS for k in per_launch}, b_track * nf,
+                              dict(algorithmic_bytes_per_stream_call=round(b_track, 1), window_pixels_per_call=round(win_px_per_call, 1), streams_per_launch=nf,
+                                   per="track() call of all streams (a launch carries up to 64 calls of every stream)"))
+    # parity in the same run: the first PAR streams' 60 calls against the oracle (the checker), after the timed region
+    PAR = 8
+    from oracle import ht_oracle as ho
+
+    ctx.camshift_init(state["rects"])
+    got = ctx.camshift_track_sequence(seq_ptrs, nf, calc_angles=True, fetch="all")
+    exact = tot = 0
+    for f in range(PAR):
+        o = ho.Camshift(True)
+        o.init_tracker(vers[0, f], state["rects"][f])
+        for k in range(CALLS):
+            sw, to = o.track(vers[(k + 1) % NV, f])
+            g = got[k, f]
+            tot += 1
+            exact += int([int(g["sw_x"]), int(g["sw_y"]), int(g["sw_width"]), int(g["sw_height"])] == list(sw) and
+                         all(float(g[q]) == to[q] for q in ("x", "y", "width", "height")) and abs(float(g["angle"]) - to["angle"]) < 1e-6)
     rec = {
-        "value": round(total_frames / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "scaling": "weak",
+        "value": round(total_frames / dt, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, **spread, "scaling": "weak",
+        "parity_exact": f"{exact}/{tot}", "parity_note": f"track() calls of the first {PAR} streams of this run vs oracle/ht_oracle.c: search window, x, y, width, height bit-exact, angle to 1e-6 rad "
+                                                       "(all 256 x 60 calls: tests/test_gpu_shapes.py, profiles/r03_camshift_parity.json)",
         "config": {"workload": WORKLOAD_TEXT["c3"], "streams_per_gpu": nf, "track_calls_per_step": CALLS, "width": W, "height": H,
                    "frame_mix": "family F only: one vote-image face per stream, moved by a seeded <= 3 px walk over 4 frame versions",
                    "steps_in_flight": depth,
                    "host_calls_per_step": "ht_detect_enqueue/collect + ht_best_faces + ht_camshift_init_batch + ONE ht_camshift_track_sequence (60 calls) + ht_camshift_sequence_collect"},
-        "roofline": dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
-                         algorithmic_bytes_per_stream_call=round(b_track, 1), window_pixels_per_call=round(win_px_per_call, 1), streams_per_launch=nf,
-                         calls_per_launch=round(CALLS / max(launches[dom], 1), 1), avg_launch_ms=round(per_launch[dom] * CALLS / max(launches[dom], 1), 5)),
+        "roofline": croof,
         "kernel_ms_per_track_call": {k: round(v, 5) for k, v in per_launch.items()},
         "kernel_rooflines": {k: dict(own_bytes_per_call=round(own[k]), gbs=round(own[k] / (per_launch[k] * 1e-3) / 1e9, 1),
                                      frac=round(own[k] / (per_launch[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) for k in per_launch},
@@ -495,12 +560,14 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
 # C5: streaming feeds
 
 
-def stream_bench(env, a):
-    """C5 (BASELINE.json configs[4]): one live 1920x1080 feed per GPU; every frame travels host -> GPU (pinned buffer,
-    PCIe) -> result on the host.  Frame 0, 30, 60, ... : full-cascade detect + camshift.initTracker on the best face
-    (facetrackr.js:97-108); every other frame: camshift.track.  A step is one frame of every feed; reports aggregate
-    frames/s and the per-frame end-to-end latency distribution."""
-    torch, dist, rank, world, local = env.torch, env.dist, env.rank, env.world, env.local
+def stream_bench(env, a, feeds=1, steps=300, warm_cycles=1, cpu_seconds=0.0):
+    """C5 (BASELINE.json configs[4]): `feeds` live 1920x1080 feeds per GPU, each on its own context (= its own HIP stream, copy
+    stream, tracker state); every frame travels host -> GPU (pinned buffer, PCIe) -> result on the host.  Per feed, frame 0 and
+    every 30th frame after its phase: full-cascade detect + camshift.initTracker on the best face (facetrackr.js:97-108); every
+    other frame: camshift.track (main.js:168-180 is this loop for one feed).  A step = one frame of every feed: the work of all
+    feeds is enqueued first and collected afterwards, so the feeds' kernels and copies overlap on the GPU.  Reports aggregate
+    frames/s (double-buffered ingest) and the per-frame end-to-end latency distribution.  Returns the record on rank 0."""
+    torch, rank, world, local = env.torch, env.rank, env.world, env.local
     from headtrackr_amd import synth
     from headtrackr_amd.api import Context
 
@@ -510,117 +577,261 @@ def stream_bench(env, a):
     hv = host.numpy()
     for k in range(nuniq):  # a face drifting 3 px / frame over a flat background
         hv[k] = synth.face_frame(W, H, [(700 + 3 * k + 40 * rank, 300 + k, 360)])
-    ctx = Context(device=local)
-    ctx.set_geometry(W, H, 1)
-    ctx.camshift_reserve(1)
     fbytes = W * H * 4
+    ctxs = []
+    for f in range(feeds):
+        cx = Context(device=local)
+        cx.set_geometry(W, H, 1)
+        cx.camshift_reserve(1)
+        ctxs.append(cx)
+    phase = [(f * 30) // feeds for f in range(feeds)]  # the feeds' detect frames are spread over the 30-frame cycle
+
+    def src(f, i):  # feed f shows the drifting face 7 f frames ahead
+        return host.data_ptr() + ((i + 7 * f) % nuniq) * fbytes
+
+    def is_detect(f, i):
+        return i == 0 or (i - phase[f]) % 30 == 0
+
+    def enqueue(f, i):
+        if is_detect(f, i):
+            ctxs[f].detect_enqueue(0)
+        else:
+            ctxs[f].camshift_track(1, calc_angles=True, fetch=False)
+
+    def collect(f, i):
+        cx = ctxs[f]
+        if is_detect(f, i):
+            best = cx.detect_collect_best(1)[0][0]
+            if best["neighbors"] > 0 and best["confidence"] > -10:
+                cx.camshift_init([[int(np.floor(best["x"])), int(np.floor(best["y"])), int(np.floor(best["width"])), int(np.floor(best["height"]))]])
+            return best
+        return cx.camshift_track_collect(1)[0]
+
     lat = {"detect": [], "track": []}
 
-    def process(i):
-        if i % 30 == 0:
-            ctx.detect_enqueue(0)
-            hits, counts = ctx.detect_collect(cap=1 << 14)
-            best = ctx.best_faces(hits, counts, 1)[0]
-            if best["neighbors"] > 0 and best["confidence"] > -10:
-                ctx.camshift_init([[int(np.floor(best["x"])), int(np.floor(best["y"])), int(np.floor(best["width"])), int(np.floor(best["height"]))]])
-            return best
-        return ctx.camshift_track(1, calc_angles=True)[0]
-
-    def frame(i):  # strictly in turn: upload, process, result — the latency of one frame on an idle pipeline
+    def frame_in_turn(i):  # every feed's frame i arrives at once: upload + work of all feeds enqueued, then collected feed by feed
         t0 = time.perf_counter()
-        ctx.upload_ptr(host.data_ptr() + (i % nuniq) * fbytes, 1)
-        out = process(i)
-        lat["detect" if i % 30 == 0 else "track"].append((time.perf_counter() - t0) * 1e3)
-        return out
+        for f in range(feeds):
+            ctxs[f].upload_ptr(src(f, i), 1)
+            enqueue(f, i)
+        for f in range(feeds):
+            collect(f, i)
+            lat["detect" if is_detect(f, i) else "track"].append((time.perf_counter() - t0) * 1e3)
 
-    for i in range(max(a.warmup, 1) * 30 + 1):
-        frame(i)
-    steps = a.steps
+    for i in range(max(warm_cycles, 1) * 30 + 1):
+        frame_in_turn(i)
     lat = {"detect": [], "track": []}
     for i in range(steps):  # latency pass (not the timed region)
-        frame(i)
-    # timed region: the same frames with double-buffered ingest (ht_upload_frames_async / ht_swap_frames): frame i+1
-    # crosses PCIe on the copy stream while frame i is processed
-    ctx.upload_async_ptr(host.data_ptr(), 1)
-    ctx.swap_frames()
-    env.fence()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        ctx.upload_async_ptr(host.data_ptr() + ((i + 1) % nuniq) * fbytes, 1)
-        last = process(i)
-        ctx.swap_frames()
-    env.fence()
-    dt = env.max_over_ranks(time.perf_counter() - t0)
-    if rank == 0:
-        allv = np.array(lat["detect"] + lat["track"])
-        pct = lambda v, q: round(float(np.percentile(np.array(v), q)), 4) if len(v) else None  # noqa: E731
-        # roofline of one 30-frame cycle (1 detect + 29 track), live HIP events on the ctx stream
-        ctx.camshift_stats(1, reset=True)
-        ctx.profile(True)
-        ctx.kernel_times(reset=True)
-        for i in range(30):
-            ctx.upload_ptr(host.data_ptr() + (i % nuniq) * fbytes, 1)
-            process(i)
-        kt = ctx.kernel_times(reset=True)
-        ctx.profile(False)
-        px, calls = ctx.camshift_stats(1, reset=True)
-        per_launch = {k: v["ms"] / v["launches"] for k, v in kt.items()}
-        det = {k: v for k, v in per_launch.items() if k in ("gray", "resample", "scan_tiles", "scan_deep")}
-        dom = max(det, key=det.get)
-        P = ctx.pyramid_bytes_per_frame
-        b_detect = 4 * W * H + 2 * P
-        ach = b_detect / (det[dom] * 1e-3) / 1e9
-        win = float(px[0]) / max(float(calls[0]), 1.0)
-        b_track = 4 * W * H + 4 * win
-        cs = {k: v for k, v in per_launch.items() if k in ("cs_hist", "cs_meanshift", "cs_track")}
-        cdom = max(cs, key=cs.get)
-        cach = b_track / (cs[cdom] * 1e-3) / 1e9
-        roofline = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
-                        algorithmic_bytes_per_frame=b_detect, frames_per_launch=1, avg_launch_ms=round(det[dom], 5),
-                        note="a single 1080p frame per launch cannot fill 256 CUs x 5 workgroups: latency-, not bandwidth-bound by construction")
-        cs_roofline = dict(bound="hbm", kernel=cdom, achieved=round(cach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(cach / HBM_PEAK_GBS, 5), traffic=None,
-                           algorithmic_bytes_per_stream_call=round(b_track, 1), window_pixels_per_call=round(win, 1), avg_launch_ms=round(cs[cdom], 5))
-        dev_ms = {k: round(v["ms"], 4) for k, v in kt.items()}
-        cpu = None
-        if world == 1 and a.cpu_seconds > 0:
-            # the reference JS on the same feed: detect on one 1080p frame, camshift.track on the following ones; a 30-frame cycle
-            # = 1 detect + 29 track calls (facetrackr's state machine after the white-balance phase)
-            fr = np.ascontiguousarray(hv[:4])
-            cd, _ = cpu_detect_baseline(fr[:2], W, H, ctx.cascade.blob, a.cpu_seconds * 0.6)
-            bx = [int(np.floor(v)) for v in (700, 300, 360, 360)]
-            ct = cpu_camshift_baseline(fr, bx, W, H, a.cpu_seconds * 0.4)
-            cyc = 1.0 / cd["value"] + 29.0 / ct["value"]
-            cpu = dict(value=round(30.0 / cyc, 3), unit="frames/s", cores=1, kind=cd["kind"] if cd["kind"] == ct["kind"] else "mixed",
-                       sample=f"one feed, 30-frame cycle = 1 detect ({cd['value']} frames/s: {cd['sample']}) + 29 camshift track ({ct['value']} calls/s: {ct['sample']})",
-                       host_cpus=cd.get("host_cpus"))
-        print(json.dumps({
-            "metric": "frames/sec streaming 1920x1080 feeds (detect every 30th frame, camshift between), end to end incl. PCIe (double-buffered ingest)",
-            "value": round(world * steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
-            "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
-            "data": "synthetic",
-            "config": {"workload": "C5: one 1920x1080 RGBA feed per GPU, host->GPU every frame, detect on frames 0,30,60,... + camshift.track otherwise",
-                       "feeds_per_gpu": 1, "width": W, "height": H, "parallelism": f"{world} feed(s), one per GPU, no collective"},
-            "latency_note": "latency_ms: upload + process + result of one frame strictly in turn (separate untimed pass over the same frames)",
-            "latency_ms": {"p50": pct(allv, 50), "p99": pct(allv, 99), "detect_p50": pct(lat["detect"], 50), "detect_max": pct(lat["detect"], 100),
-                           "track_p50": pct(lat["track"], 50), "track_p99": pct(lat["track"], 99)},
-            "last_track": [float(last["x"]), float(last["y"]), float(last["width"]), float(last["height"])],
-            "roofline": roofline, "camshift_roofline": cs_roofline, "device_ms_per_30_frame_cycle": dev_ms,
-            "cpu_baseline": cpu, "vs_cpu": round(world * steps / dt / cpu["value"], 1) if cpu else None}), flush=True)
+        frame_in_turn(i)
+    # timed region: the same frames with double-buffered ingest (ht_upload_frames_async / ht_swap_frames): frame i+1 of every feed
+    # crosses PCIe on its copy stream while frame i is processed
+    last = [None] * feeds
+
+    def block(k):
+        for f in range(feeds):
+            ctxs[f].upload_async_ptr(src(f, 0), 1)
+            ctxs[f].swap_frames()
+        for i in range(k):
+            for f in range(feeds):
+                ctxs[f].upload_async_ptr(src(f, i + 1), 1)
+                enqueue(f, i)
+            for f in range(feeds):
+                last[f] = collect(f, i)
+                ctxs[f].swap_frames()
+
+    dts = env.timed_rounds(block, steps, a.rounds if a.workload == "c5" else 1, target_s=0.5)
+    dt, spread = round_stats(dts, steps)
+    graph_launches = sum(cx.graph_launches for cx in ctxs)
+    for cx in ctxs[1:]:
+        cx.close()
+    ctx = ctxs[0]
+    if rank != 0:
+        ctx.close()
+        return None
+    allv = np.array(lat["detect"] + lat["track"])
+    pct = lambda v, q: round(float(np.percentile(np.array(v), q)), 4) if len(v) else None  # noqa: E731
+    # rooflines of one 30-frame cycle of ONE feed (1 detect + 29 track), live HIP events on the ctx stream; the dominant kernel of
+    # each path = the one with the largest device time per cycle
+    ctx.camshift_stats(1, reset=True)
+    ctx.profile(True)
+    ctx.kernel_times(reset=True)
+    for i in range(30):
+        ctx.upload_ptr(src(0, i), 1)
+        enqueue(0, i)
+        collect(0, i)
+    kt = ctx.kernel_times(reset=True)
+    ctx.profile(False)
+    px, calls = ctx.camshift_stats(1, reset=True)
+    det_names, cs_names = ("gray", "resample", "scan_tiles", "scan_deep"), ("cs_hist", "cs_lut", "cs_meanshift", "cs_track")
+    P = ctx.pyramid_bytes_per_frame
+    b_detect = 4 * W * H + 2 * P
+    win = float(px[0]) / max(float(calls[0]), 1.0)
+    b_track = 4 * W * H + 4 * win
+    ncs = max(int(calls[0]), 1)
+    roofline = dominant_roofline({k: kt[k]["ms"] for k in det_names if k in kt}, {k: kt[k]["launches"] for k in det_names if k in kt}, b_detect,
+                                 dict(algorithmic_bytes_per_frame=b_detect, frames_per_step=1, per="detect frame",
+                                      note="a single 1080p frame per launch cannot fill 256 CUs x 6 workgroups: latency-, not bandwidth-bound by construction"))
+    cs_roofline = dominant_roofline({k: kt[k]["ms"] / ncs for k in cs_names if k in kt}, {k: kt[k]["launches"] / ncs for k in cs_names if k in kt}, b_track,
+                                    dict(algorithmic_bytes_per_stream_call=round(b_track, 1), window_pixels_per_call=round(win, 1), per="track() call"))
+    det_ms = sum(kt[k]["ms"] for k in det_names if k in kt)
+    cs_ms = sum(kt[k]["ms"] for k in cs_names if k in kt) / ncs
+    dev_ms = {k: round(v["ms"], 4) for k, v in kt.items()}
+    cpu = None
+    if world == 1 and cpu_seconds > 0:
+        # the reference JS on the same feed: detect on one 1080p frame, camshift.track on the following ones; a 30-frame cycle
+        # = 1 detect + 29 track calls (facetrackr's state machine after the white-balance phase)
+        fr = np.ascontiguousarray(hv[:4])
+        cd, _ = cpu_detect_baseline(fr[:2], W, H, ctx.cascade.blob, cpu_seconds * 0.6)
+        bx = [int(np.floor(v)) for v in (700, 300, 360, 360)]
+        ct = cpu_camshift_baseline(fr, bx, W, H, cpu_seconds * 0.4)
+        cyc = 1.0 / cd["value"] + 29.0 / ct["value"]
+        cpu = dict(value=round(30.0 / cyc, 3), unit="frames/s", cores=1, kind=cd["kind"] if cd["kind"] == ct["kind"] else "mixed",
+                   sample=f"one feed, 30-frame cycle = 1 detect ({cd['value']} frames/s: {cd['sample']}) + 29 camshift track ({ct['value']} calls/s: {ct['sample']})",
+                   host_cpus=cd.get("host_cpus"))
+    fps = world * feeds * steps / dt
+    rec = {
+        "value": round(fps, 2), "unit": "frames/s", "steps": steps, "warmup": warm_cycles, **spread, "scaling": "weak",
+        "config": {"workload": f"C5: {feeds} live 1920x1080 RGBA feed(s) per GPU, host->GPU every frame (pinned, double-buffered), detect on every 30th frame of a feed + camshift.track otherwise",
+                   "feeds_per_gpu": feeds, "width": W, "height": H, "detect_phase_per_feed": phase,
+                   "parallelism": f"{world * feeds} feed(s): {feeds} per GPU on their own contexts / HIP streams, {world} GPU(s), no collective"},
+        "per_feed_fps": round(fps / (world * feeds), 2),
+        "latency_note": "latency_ms: all feeds' frame i arrive at once; upload + work of every feed enqueued, then collected feed by feed; one sample per feed and frame (separate untimed pass)",
+        "latency_ms": {"p50": pct(allv, 50), "p99": pct(allv, 99), "detect_p50": pct(lat["detect"], 50), "detect_max": pct(lat["detect"], 100),
+                       "track_p50": pct(lat["track"], 50), "track_p99": pct(lat["track"], 99), "samples": int(len(allv))},
+        "detect_graph_replays": int(graph_launches),
+        "last_track": [float(last[0]["x"]), float(last[0]["y"]), float(last[0]["width"]), float(last[0]["height"])] if last[0] is not None else None,
+        "roofline": roofline, "camshift_roofline": cs_roofline,
+        "device_ms": {"detect_frame": round(det_ms, 4), "track_call": round(cs_ms, 4), "per_30_frame_cycle": dev_ms},
+        "cpu_baseline": cpu, "vs_cpu": round(fps / cpu["value"], 1) if cpu else None}
     ctx.close()
+    return rec
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the JavaScript host (north_star: "Host code stays JavaScript (Node)"): the same C ABI driven from Node through the N-API addon
+
+
+def js_host_bench(seconds=2.0):
+    """tests/js/bench_host.js on this GPU: detect frames/s at the C2 shape from Node — ccv.detect_objects_batch on host frames (PCIe
+    every call) and ccv.DeviceBatch (frames resident in HBM, enqueue / collect-best / re-enqueue over 3 contexts: this file's
+    headline loop, driven from JavaScript) — and the per-call latency of the drop-in facetrackr.Tracker.track() at 320x240, next to
+    the unmodified reference JS on the same frames.  None when node or the addon is missing."""
+    from headtrackr_amd import synth
+
+    node = shutil.which("node")
+    script = os.path.join(ROOT, "tests", "js", "bench_host.js")
+    if not node or not os.path.exists(script) or not os.path.exists(os.path.join(ROOT, "headtrackr_amd", "js", "headtrackr_hip.node")):
+        return None
+    W, H, n, nt = 320, 240, 256, 30
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            c2 = os.path.join(td, "c2.raw")
+            synth.mixed_batch(n, W, H, seed0=1234).tofile(c2)
+            tr = os.path.join(td, "track.raw")
+            np.stack([synth.face_frame(W, H, [(90 + 2 * k, 50 + k, 96)]) for k in range(nt)]).tofile(tr)
+            r = subprocess.run([node, script, str(seconds), c2, str(n), tr, str(nt)], capture_output=True, text=True, timeout=seconds * 20 + 240)
+        j = json.loads(r.stdout.strip().splitlines()[-1])
+        j["config"] = {"workload": f"JS host (Node + N-API addon): {n} x {W}x{H} detect per batch (the C2 frames) and facetrackr.Tracker.track() on a {W}x{H} canvas with one drifting face"}
+        return j
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# launcher / stub
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) under torch.distributed.run and pass their
+    output through.  Fails loudly when fewer than N GPUs are visible."""
+    import socket
+
+    stub = os.environ.get("HT_BENCH_STUB") == "1"
+    if not stub:
+        import torch
+
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible to this process — refusing to report an N-GPU number from fewer devices")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HT_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def stub_bench(env, a):
+    """HT_BENCH_STUB=1 (tests/test_distributed_cpu.py): the N-rank plumbing of this file — launcher, rank environment, timed rounds
+    with barriers and max over ranks, the all-gather of best-face records and its verification, the one JSON line of rank 0 — on
+    gloo / CPU tensors with a stand-in step.  Never a measurement: the line says so."""
+    torch, dist, rank, world = env.torch, env.dist, env.rank, env.world
+    from headtrackr_amd import distributed as hd
+    from headtrackr_amd.native import RECT_DTYPE
+
+    nf = a.frames or 6
+    total = nf * world
+    best = np.zeros(nf, dtype=RECT_DTYPE)
+    best["x"] = 10.0 * rank + np.arange(nf)
+    best["confidence"] = -1.0 - rank
+    best["neighbors"] = 1 + (np.arange(nf) % 3)
+    state = {}
+
+    def run_steps(k):
+        for _ in range(k):
+            time.sleep(0.0005)  # the stand-in for a detect step
+            rec = hd.pack_best_records(best, rank * nf, nf)
+            state["rec"] = rec
+            state["gathered"] = hd.allgather_records(torch.from_numpy(rec), world, nf)
+
+    run_steps(max(a.warmup, 1))
+    dts = env.timed_rounds(run_steps, a.steps, a.rounds, target_s=0.05)
+    dt, spread = round_stats(dts, a.steps)
+    everyone = [None] * world
+    if world > 1:
+        dist.all_gather_object(everyone, state["rec"])
+    else:
+        everyone = [state["rec"]]
+    if rank != 0:
+        return None
+    got = state["gathered"].numpy()
+    ok = all(np.array_equal(got[r], everyone[r]) for r in range(world))
+    return {"metric": "STUB — launcher / collective plumbing only, not a measurement", "value": round(total * a.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, **spread, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "stub",
+            "config": {"workload": "stub", "frames_per_gpu": nf, "frames_total": total}, "ranks": world, "backend": "gloo", "allgather_verified": bool(ok),
+            "launched_by_bench": os.environ.get("HT_BENCH_LAUNCHED") == "1"}
 
 
 def main():
     a = parse()
+    stub = os.environ.get("HT_BENCH_STUB") == "1"
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(a)  # does not return
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: one rank per GPU (run `python bench.py --gpus N` without a launcher, or pass matching values)")
+    if stub:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        line = stub_bench(Env(torch, dist, rank, world, local, stub=True), a)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -629,7 +840,9 @@ def main():
     t_run = time.perf_counter()
 
     if a.workload == "c5":
-        stream_bench(env, a)
+        prim = stream_bench(env, a, feeds=max(1, a.feeds), steps=a.steps, warm_cycles=max(a.warmup, 1), cpu_seconds=a.cpu_seconds)
+        metric = "frames/sec streaming 1920x1080 feeds (detect every 30th frame, camshift between), end to end incl. PCIe (double-buffered ingest)"
+        sub = {}
     else:
         if a.workload == "c3":
             prim = c3_bench(env, a, a.steps, a.warmup, a.cpu_seconds)
@@ -640,28 +853,38 @@ def main():
             metric = f"frames/sec full-cascade detect at {W}x{H}"
         sub = {}
         if a.workload == "c2" and a.scaling == "weak" and not a.no_sub:
-            # the rest of BASELINE.json's metric in the same line: 1280x720 detect (per-GPU batch of configs[3]; weak and strong)
-            # and detect + camshift (configs[2]), each with its own bounded budget
+            # the rest of BASELINE.json's metric in the same line: 1280x720 detect (per-GPU batch of configs[3]; weak and strong),
+            # detect + camshift (configs[2]) and the streaming config (configs[4]), each with its own bounded budget
             tag = "c4_1gpu" if world == 1 else "c4"
             sub[tag] = detect_bench(env, a, "c4", SUB_STEPS["c4"], 10, cpu_seconds=a.cpu_seconds, prewarm=0.1, full=False)
             sub["c4_strong"] = detect_bench(env, a, "c4", SUB_STEPS["c4_strong"], 4, scaling="strong", cpu_seconds=0, full=False)
             sub["c3"] = c3_bench(env, a, SUB_STEPS["c3"], 2, a.cpu_seconds * 0.7)
-        if rank == 0:
-            copy_gbs = device_copy_ceiling(torch)
-            for r in [prim] + [v for v in sub.values() if v]:
-                if r.get("roofline"):
-                    r["roofline"]["device_copy_gbs"] = round(copy_gbs, 1)
-                    r["roofline"]["frac_of_device_copy"] = round(r["roofline"]["achieved"] / copy_gbs, 5)
-            line = {"metric": metric, "value": prim["value"], "unit": "frames/s", "n_gpus": world, "steps": prim["steps"], "warmup": prim["warmup"],
-                    "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": prim["scaling"], "vs_baseline": None, "dtype": "u8",
-                    "data": "synthetic"}
-            line.update({k: v for k, v in prim.items() if k not in line})
-            if sub:
-                line["sub"] = sub
-                if sub.get("c4_1gpu") and sub["c4_1gpu"].get("vs_cpu"):
-                    line["north_star_720p_vs_reference_js"] = sub["c4_1gpu"]["vs_cpu"]  # target: >= 30x on 1280x720 detect at 1 GPU
-            line["bench_wall_s"] = round(time.perf_counter() - t_run, 1)
-            print(json.dumps(line), flush=True)
+            one = stream_bench(env, a, feeds=1, steps=SUB_STEPS["c5"], cpu_seconds=a.cpu_seconds * 0.7)
+            many = stream_bench(env, a, feeds=8, steps=SUB_STEPS["c5"], cpu_seconds=0)
+            if rank == 0:
+                many["one_feed"] = one
+                many["feeds_8_vs_1"] = round(many["value"] / one["value"], 2)
+                many["cpu_baseline"] = one["cpu_baseline"]
+                many["vs_cpu"] = round(many["value"] / one["cpu_baseline"]["value"], 1) if one.get("cpu_baseline") else None
+            sub["c5"] = many
+            if rank == 0 and world == 1:
+                sub["js_host"] = js_host_bench(2.0)
+    if rank == 0:
+        copy_gbs = device_copy_ceiling(torch)
+        for r in [prim] + [v for v in sub.values() if v]:
+            if r.get("roofline"):
+                r["roofline"]["device_copy_gbs"] = round(copy_gbs, 1)
+                r["roofline"]["frac_of_device_copy"] = round(r["roofline"]["achieved"] / copy_gbs, 5)
+        line = {"metric": metric, "value": prim["value"], "unit": "frames/s", "n_gpus": world, "ranks": world, "steps": prim["steps"], "warmup": prim["warmup"],
+                "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": prim["scaling"], "vs_baseline": None, "dtype": "u8",
+                "data": "synthetic", "launched_by_bench": os.environ.get("HT_BENCH_LAUNCHED") == "1"}
+        line.update({k: v for k, v in prim.items() if k not in line})
+        if sub:
+            line["sub"] = sub
+            if sub.get("c4_1gpu") and sub["c4_1gpu"].get("vs_cpu"):
+                line["north_star_720p_vs_reference_js"] = sub["c4_1gpu"]["vs_cpu"]  # target: >= 30x on 1280x720 detect at 1 GPU
+        line["bench_wall_s"] = round(time.perf_counter() - t_run, 1)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

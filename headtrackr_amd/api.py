@@ -36,7 +36,6 @@ class Context:
         self.width = self.height = 0
         self._collected_n = 0
         self.nframes = 0   # frames currently bound (upload / bind_device / swap_frames)
-        self._enq_n = 0    # frames of the batch enqueued last: what the collect calls report on (ht_ctx.enq_nframes)
 
     # -- plumbing -------------------------------------------------------------------------------------------
     def close(self):
@@ -112,12 +111,11 @@ class Context:
     # -- detect -----------------------------------------------------------------------------------------------
     def detect_enqueue(self, flags: int = HT_INPUT_RGBA):
         self._check(self._lib.ht_detect_enqueue(self._h, flags))
-        self._enq_n = self.nframes
 
     # The library sizes what it writes (counts[], best[]) by the batch that was ENQUEUED, not by what is bound at collect time
-    # (a streaming host binds or swaps in the next frames in between): the buffers below follow `_enq_n`.
+    # (a streaming host binds or swaps in the next frames in between): the buffers below follow ht_frames_enqueued.
     def detect_collect(self, cap: int = 1 << 16):
-        n = self._collected_n = self._enq_n
+        n = self._collected_n = int(self._lib.ht_frames_enqueued(self._h))  # the library's own count of the batch in flight
         buf = getattr(self, "_hitbuf", None)
         if buf is None or len(buf) < cap:
             buf = self._hitbuf = np.empty(cap, dtype=HIT_DTYPE)  # reused across calls
@@ -128,7 +126,7 @@ class Context:
 
     def detect_collect_best(self, min_neighbors: int = 1, out: np.ndarray | None = None):
         """ht_detect_collect + ht_best_faces in one C call: (best rect per frame of the enqueued batch, raw hit count)."""
-        n = self._collected_n = self._enq_n
+        n = self._collected_n = int(self._lib.ht_frames_enqueued(self._h))  # the library's own count of the batch in flight
         if out is None or len(out) < n:
             out = np.zeros(max(1, n), dtype=RECT_DTYPE)
         total = C.c_uint32(0)
@@ -138,16 +136,11 @@ class Context:
     def detect_collect_best_requeue(self, min_neighbors: int = 1, out: np.ndarray | None = None, next_flags: int = HT_INPUT_RGBA):
         """detect_collect_best, and the next batch of the bound frames is enqueued as soon as this batch's raw hits are on the host
         (before they are sorted and grouped)."""
-        n = self._collected_n = self._enq_n
+        n = self._collected_n = int(self._lib.ht_frames_enqueued(self._h))  # the library's own count of the batch in flight
         if out is None or len(out) < n:
             out = np.zeros(max(1, n), dtype=RECT_DTYPE)
         total = C.c_uint32(0)
-        self._enq_n = self.nframes  # the batch the library enqueues inside this call covers the frames bound NOW
-        try:
-            self._check(self._lib.ht_detect_collect_best_requeue(self._h, min_neighbors, out.ctypes.data, C.byref(total), next_flags))
-        except HtError:
-            self._enq_n = 0  # a failed collect leaves nothing enqueued that this wrapper could size buffers for
-            raise
+        self._check(self._lib.ht_detect_collect_best_requeue(self._h, min_neighbors, out.ctypes.data, C.byref(total), next_flags))
         return out[:n], total.value
 
     def detect_raw(self, frames: np.ndarray, flags: int = HT_INPUT_RGBA, cap: int = 1 << 16):

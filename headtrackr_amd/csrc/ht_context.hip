@@ -756,6 +756,49 @@ extern "C" ht_status ht_bind_frames_device(ht_ctx *c, const void *dev_rgba, int3
     return HT_OK;
 }
 
+extern "C" int32_t ht_frames_bound(const ht_ctx *c) { return c ? c->nframes : 0; }
+extern "C" int32_t ht_frames_enqueued(const ht_ctx *c) { return (c && c->enqueued) ? c->enq_nframes : 0; }
+
+extern "C" ht_status ht_host_alloc(size_t bytes, void **out) {
+    if (!out || bytes == 0) return HT_ERR_INVALID;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return ht_fail(nullptr, HT_ERR_NOMEM, "ht_host_alloc: hipHostMalloc failed");
+    }
+    return HT_OK;
+}
+extern "C" void ht_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+extern "C" ht_status ht_device_alloc(ht_ctx *c, size_t bytes, void **out) {
+    if (!c || !out || bytes == 0) return HT_ERR_INVALID;
+    *out = nullptr;
+    HT_HIP(c, hipSetDevice(c->device));
+    if (hipMalloc(out, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return ht_fail(c, HT_ERR_NOMEM, "ht_device_alloc: hipMalloc failed");
+    }
+    return HT_OK;
+}
+extern "C" ht_status ht_device_free(ht_ctx *c, void *p) {
+    if (!c) return HT_ERR_INVALID;
+    if (!p) return HT_OK;
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipStreamSynchronize(c->stream));  // nothing enqueued on this context may still read it
+    if (c->d_frames == p) c->d_frames = nullptr, c->nframes = 0;
+    HT_HIP(c, hipFree(p));
+    return HT_OK;
+}
+extern "C" ht_status ht_device_upload(ht_ctx *c, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!c || !dst_dev || !src_host) return HT_ERR_INVALID;
+    if (bytes == 0) return HT_OK;
+    HT_HIP(c, hipSetDevice(c->device));
+    HT_HIP(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    HT_HIP(c, hipStreamSynchronize(c->stream));
+    return HT_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // detect
 

@@ -16,6 +16,21 @@
 //   deviceCount() -> number of visible GPUs
 //   allgatherBest([ctx0, ctx1, ...], [Float64Array(6*f) per rank: x,y,width,height,confidence,neighbors], framesPerRank)
 //        -> Float64Array(6 * nranks * framesPerRank): every rank's best-face rects after the RCCL all-gather (ht_allgather_best_faces)
+//
+// The pipelined path (what the throughput numbers are made of; every C-ABI export has a JS name):
+//   hostAlloc(bytes) -> Uint8Array over PINNED host memory (ht_host_alloc)         deviceAlloc(ctx, bytes) -> device buffer (external)
+//   deviceUpload(ctx, dev, byteOffset, Uint8Array)      deviceFree(ctx, dev)
+//   upload(ctx, rgba, n, w, h)            ht_upload_frames: bind host frames once, then any number of *Bound calls on them
+//   bindDevice(ctx, dev, byteOffset, n)   ht_bind_frames_device
+//   uploadAsync(ctx, rgba, n) / swapFrames(ctx)          double-buffered ingest (rgba should come from hostAlloc)
+//   detectEnqueue(ctx, flags)             ht_detect_enqueue           detectCollect(ctx) -> hits object (ht_detect_collect)
+//   collectBest(ctx, minNeighbors, requeueFlags = -1) -> {best: Float64Array(6 n), hits}   ht_detect_collect_best(_requeue)
+//   detectWhitebalance(ctx, n) -> Float64Array(n)        whitebalanceBound(ctx, n) -> Float64Array(n)
+//   camshiftInitBound(ctx, n, first, Int32Array rects)   camshiftTrackBound(ctx, n, first, calcAngles, fetch = true) -> Float64Array(9n) | undefined
+//   camshiftTrackCollect(ctx, n) -> Float64Array(9n)
+//   camshiftTrackSequence(ctx, first, n, calcAngles, dev, Float64Array byteOffsets[ncalls], frameStride, outAll, fetch) -> Float64Array | undefined
+//   camshiftSequenceCollect(ctx, n, ncalls, outAll) -> Float64Array
+//   framesBound(ctx), framesEnqueued(ctx), graphLaunches(ctx)
 #include <node_api.h>
 
 #include <cstdint>
@@ -49,7 +64,7 @@ napi_value throw_ht(napi_env env, ht_ctx *ctx, ht_status st, const char *where) 
 // takes `mu` for the duration of its C-ABI calls, so overlapping calls run one after the other, in lock-acquisition order.
 struct Slot {
     ht_ctx *ctx = nullptr;
-    std::mutex mu;
+    std::recursive_mutex mu;  // recursive: a GC finalizer (device buffers) may run on the JS thread inside an entry point that holds it
 };
 
 bool get_slot(napi_env env, napi_value v, Slot **out) {
@@ -64,13 +79,13 @@ bool get_slot(napi_env env, napi_value v, Slot **out) {
 
 // Locks the slot and yields its context; throws (and returns false) when the context was destroyed.
 struct Locked {
-    std::unique_lock<std::mutex> lk;
+    std::unique_lock<std::recursive_mutex> lk;
     ht_ctx *ctx = nullptr;
 };
 bool lock_ctx(napi_env env, napi_value v, Locked *out) {
     Slot *s = nullptr;
     if (!get_slot(env, v, &s)) return false;
-    out->lk = std::unique_lock<std::mutex>(s->mu);
+    out->lk = std::unique_lock<std::recursive_mutex>(s->mu);
     out->ctx = s->ctx;
     if (!out->ctx) {
         out->lk.unlock();
@@ -164,7 +179,7 @@ napi_value Destroy(napi_env env, napi_callback_info info) {
     void *p = nullptr;
     if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
         Slot *slot = static_cast<Slot *>(p);
-        std::lock_guard<std::mutex> lk(slot->mu);  // waits for an asynchronous job in flight on this context
+        std::lock_guard<std::recursive_mutex> lk(slot->mu);  // waits for an asynchronous job in flight on this context
         if (slot->ctx) ht_destroy(slot->ctx);
         slot->ctx = nullptr;
     }
@@ -224,7 +239,7 @@ struct DetectJob {
 };
 
 void run_detect(DetectJob *j) {
-    std::lock_guard<std::mutex> lk(j->slot->mu);
+    std::lock_guard<std::recursive_mutex> lk(j->slot->mu);
     ht_ctx *ctx = j->slot->ctx;
     if (!ctx) {
         j->st = HT_ERR_STATE;
@@ -567,6 +582,413 @@ napi_value AllgatherBest(napi_env env, napi_callback_info info) {
     return ta;
 }
 
+// ---- pipelined path ------------------------------------------------------------------------------------------------------------
+
+void finalize_pinned(napi_env, void *data, void *) { ht_host_free(data); }
+
+napi_value HostAlloc(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    double bytes = 0;
+    if (argc < 1 || napi_get_value_double(env, argv[0], &bytes) != napi_ok || !(bytes >= 1) || bytes > 1e12) {
+        napi_throw_type_error(env, nullptr, "hostAlloc(bytes)");
+        return nullptr;
+    }
+    void *p = nullptr;
+    ht_status st = ht_host_alloc((size_t)bytes, &p);
+    if (st != HT_OK) return throw_ht(env, nullptr, st, "ht_host_alloc");
+    napi_value ab, ta;
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, finalize_pinned, nullptr, &ab) != napi_ok) {
+        ht_host_free(p);
+        napi_throw_error(env, nullptr, "hostAlloc: napi_create_external_arraybuffer failed");
+        return nullptr;
+    }
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, (size_t)bytes, ab, 0, &ta));
+    return ta;
+}
+
+// a device buffer: freed explicitly (deviceFree) or, at the latest, when the JS handle is collected — through the context it was
+// allocated on, which the handle keeps alive
+struct DevBuf {
+    Slot *slot = nullptr;
+    void *ptr = nullptr;
+    size_t bytes = 0;
+    napi_ref ctx_ref = nullptr;
+};
+void finalize_devbuf(napi_env env, void *data, void *) {
+    DevBuf *d = static_cast<DevBuf *>(data);
+    if (d->ptr && d->slot) {
+        std::lock_guard<std::recursive_mutex> lk(d->slot->mu);
+        if (d->slot->ctx) (void)ht_device_free(d->slot->ctx, d->ptr);
+    }
+    if (d->ctx_ref) napi_delete_reference(env, d->ctx_ref);
+    delete d;
+}
+bool get_devbuf(napi_env env, napi_value v, DevBuf **out) {
+    void *p = nullptr;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<DevBuf *>(p)->ptr) {
+        napi_throw_type_error(env, nullptr, "expected a live device buffer (deviceAlloc)");
+        return false;
+    }
+    *out = static_cast<DevBuf *>(p);
+    return true;
+}
+
+napi_value DeviceAlloc(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    double bytes = 0;
+    if (argc < 2 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (napi_get_value_double(env, argv[1], &bytes) != napi_ok || !(bytes >= 1) || bytes > 2.5e11) {
+        napi_throw_type_error(env, nullptr, "deviceAlloc(ctx, bytes)");
+        return nullptr;
+    }
+    DevBuf *d = new DevBuf();
+    ht_status st = ht_device_alloc(L.ctx, (size_t)bytes, &d->ptr);
+    if (st != HT_OK) {
+        delete d;
+        return throw_ht(env, L.ctx, st, "ht_device_alloc");
+    }
+    get_slot(env, argv[0], &d->slot);
+    d->bytes = (size_t)bytes;
+    napi_create_reference(env, argv[0], 1, &d->ctx_ref);
+    napi_value ext;
+    NAPI_OK(napi_create_external(env, d, finalize_devbuf, nullptr, &ext));
+    return ext;
+}
+
+napi_value DeviceFree(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    DevBuf *d = nullptr;
+    if (argc < 2 || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
+    ht_status st = ht_device_free(L.ctx, d->ptr);
+    d->ptr = nullptr;
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_device_free");
+    return nullptr;
+}
+
+bool get_offset(napi_env env, napi_value v, size_t *out) {
+    double d = 0;
+    if (napi_get_value_double(env, v, &d) != napi_ok || !(d >= 0) || d > 2.5e11) return false;
+    *out = (size_t)d;
+    return true;
+}
+
+napi_value DeviceUpload(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    DevBuf *d = nullptr;
+    uint8_t *src = nullptr;
+    size_t len = 0, off = 0;
+    if (argc < 4 || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
+    if (!get_offset(env, argv[2], &off) || !get_bytes(env, argv[3], &src, &len) || off + len > d->bytes) {
+        napi_throw_range_error(env, nullptr, "deviceUpload(ctx, dev, byteOffset, Uint8Array): outside the device buffer");
+        return nullptr;
+    }
+    ht_status st = ht_device_upload(L.ctx, static_cast<char *>(d->ptr) + off, src, len);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_device_upload");
+    return nullptr;
+}
+
+napi_value Upload(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    FrameArgs a;
+    if (argc < 5 || !parse_frames(env, argv, &a)) return nullptr;
+    ht_status st = bind_host_frames(a);
+    if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_upload_frames");
+    return nullptr;
+}
+
+napi_value BindDevice(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    DevBuf *d = nullptr;
+    size_t off = 0, stride = 0;
+    int32_t n = 0;
+    if (argc < 5 || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
+    if (!get_offset(env, argv[2], &off) || !get_i32(env, argv[3], &n) || !get_offset(env, argv[4], &stride) || n <= 0 || off + (size_t)n * stride > d->bytes) {
+        napi_throw_range_error(env, nullptr, "bindDevice(ctx, dev, byteOffset, n, frameStride): outside the device buffer");
+        return nullptr;
+    }
+    ht_status st = ht_bind_frames_device(L.ctx, static_cast<char *>(d->ptr) + off, n, stride);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_bind_frames_device");
+    return nullptr;
+}
+
+napi_value UploadAsync(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    uint8_t *src = nullptr;
+    size_t len = 0;
+    int32_t n = 0;
+    if (argc < 3 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (!get_bytes(env, argv[1], &src, &len) || !get_i32(env, argv[2], &n) || n <= 0 || len % (size_t)n) {
+        napi_throw_type_error(env, nullptr, "uploadAsync(ctx, Uint8Array rgba (n frames, ideally from hostAlloc), n)");
+        return nullptr;
+    }
+    ht_status st = ht_upload_frames_async(L.ctx, src, n, len / (size_t)n);  // rgba must stay untouched until swapFrames
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_upload_frames_async");
+    return nullptr;
+}
+
+napi_value SwapFrames(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    ht_status st = ht_swap_frames(L.ctx);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_swap_frames");
+    return nullptr;
+}
+
+napi_value DetectEnqueue(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    int32_t fl = 0;
+    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (argc > 1) get_i32(env, argv[1], &fl);
+    ht_status st = ht_detect_enqueue(L.ctx, (uint32_t)fl);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_detect_enqueue");
+    return nullptr;
+}
+
+napi_value DetectCollect(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    DetectJob j;
+    j.n = ht_frames_enqueued(L.ctx);  // the batch in flight, not whatever is bound by now
+    j.hits.resize(1u << 16);
+    j.counts.assign((size_t)j.n, 0);
+    j.st = ht_detect_collect(L.ctx, j.hits.data(), (uint32_t)j.hits.size(), j.counts.data(), &j.total);
+    if (j.st == HT_ERR_CAPACITY && j.total > j.hits.size()) {
+        napi_throw_error(env, nullptr, "detectCollect: more than 65536 raw hits in one batch; use collectBest or smaller batches");
+        return nullptr;
+    }
+    if (j.st != HT_OK) return throw_ht(env, L.ctx, j.st, "ht_detect_collect");
+    return pack_hits(env, j);
+}
+
+napi_value CollectBest(napi_env env, napi_callback_info info) {
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    int32_t mn = 1, rq = -1;
+    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (argc > 1) get_i32(env, argv[1], &mn);
+    if (argc > 2) get_i32(env, argv[2], &rq);
+    const int32_t n = ht_frames_enqueued(L.ctx);
+    std::vector<ht_rect> best((size_t)(n > 0 ? n : 1));
+    uint32_t total = 0;
+    ht_status st = rq >= 0 ? ht_detect_collect_best_requeue(L.ctx, mn, best.data(), &total, (uint32_t)rq) : ht_detect_collect_best(L.ctx, mn, best.data(), &total);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_detect_collect_best");
+    napi_value obj, ab, ta, v;
+    void *p = nullptr;
+    NAPI_OK(napi_create_object(env, &obj));
+    NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 6 * 8, &p, &ab));
+    double *d = static_cast<double *>(p);
+    for (int i = 0; i < n; i++) {
+        const ht_rect &r = best[(size_t)i];
+        d[6 * i] = r.x, d[6 * i + 1] = r.y, d[6 * i + 2] = r.width, d[6 * i + 3] = r.height, d[6 * i + 4] = r.confidence, d[6 * i + 5] = r.neighbors;
+    }
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, (size_t)n * 6, ab, 0, &ta));
+    NAPI_OK(napi_set_named_property(env, obj, "best", ta));
+    NAPI_OK(napi_create_uint32(env, total, &v));
+    NAPI_OK(napi_set_named_property(env, obj, "hits", v));
+    return obj;
+}
+
+napi_value f64_result(napi_env env, const double *src, size_t n) {
+    napi_value ab, ta;
+    void *p = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, n * 8, &p, &ab));
+    if (n) std::memcpy(p, src, n * 8);
+    NAPI_OK(napi_create_typedarray(env, napi_float64_array, n, ab, 0, &ta));
+    return ta;
+}
+
+napi_value wb_common(napi_env env, napi_callback_info info, bool fused) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    int32_t n = 0;
+    if (argc < 2 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (!get_i32(env, argv[1], &n) || n <= 0) {
+        napi_throw_type_error(env, nullptr, "(ctx, n)");
+        return nullptr;
+    }
+    std::vector<double> out((size_t)n);
+    ht_status st = fused ? ht_detect_whitebalance(L.ctx, out.data(), n) : ht_whitebalance_batch(L.ctx, out.data(), n);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, fused ? "ht_detect_whitebalance" : "ht_whitebalance_batch");
+    return f64_result(env, out.data(), out.size());
+}
+napi_value DetectWhitebalance(napi_env env, napi_callback_info info) { return wb_common(env, info, true); }
+napi_value WhitebalanceBound(napi_env env, napi_callback_info info) { return wb_common(env, info, false); }
+
+napi_value trackobjs_result(napi_env env, const std::vector<ht_cs_trackobj> &out) {
+    std::vector<double> d(out.size() * 9);
+    for (size_t i = 0; i < out.size(); i++) {
+        const ht_cs_trackobj &o = out[i];
+        double *r = d.data() + 9 * i;
+        r[0] = o.x, r[1] = o.y, r[2] = o.width, r[3] = o.height, r[4] = o.angle;
+        r[5] = o.sw_x, r[6] = o.sw_y, r[7] = o.sw_width, r[8] = o.sw_height;
+    }
+    return f64_result(env, d.data(), d.size());
+}
+
+napi_value CamshiftInitBound(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    int32_t n = 0, first = 0;
+    napi_typedarray_type t;
+    size_t len;
+    void *p;
+    napi_value ab;
+    size_t off;
+    if (argc < 4 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (!get_i32(env, argv[1], &n) || !get_i32(env, argv[2], &first) || n <= 0 || napi_get_typedarray_info(env, argv[3], &t, &len, &p, &ab, &off) != napi_ok ||
+        t != napi_int32_array || len < (size_t)n * 4) {
+        napi_throw_type_error(env, nullptr, "camshiftInitBound(ctx, n, first, Int32Array rects[4n])");
+        return nullptr;
+    }
+    ht_status st = ht_camshift_init_batch(L.ctx, first, n, static_cast<const ht_cs_rect *>(p));
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_camshift_init_batch");
+    return nullptr;
+}
+
+napi_value CamshiftTrackBound(napi_env env, napi_callback_info info) {
+    size_t argc = 5;
+    napi_value argv[5];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    int32_t n = 0, first = 0, calc = 1;
+    bool fetch = true;
+    if (argc < 4 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (!get_i32(env, argv[1], &n) || !get_i32(env, argv[2], &first) || !get_i32(env, argv[3], &calc) || n <= 0) {
+        napi_throw_type_error(env, nullptr, "camshiftTrackBound(ctx, n, first, calcAngles, fetch)");
+        return nullptr;
+    }
+    if (argc > 4) napi_get_value_bool(env, argv[4], &fetch);
+    std::vector<ht_cs_trackobj> out((size_t)n);
+    ht_status st = ht_camshift_track_batch(L.ctx, first, n, calc, fetch ? out.data() : nullptr);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_camshift_track_batch");
+    if (!fetch) return nullptr;
+    return trackobjs_result(env, out);
+}
+
+napi_value CamshiftTrackCollect(napi_env env, napi_callback_info info) {
+    size_t argc = 2;
+    napi_value argv[2];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    int32_t n = 0;
+    if (argc < 2 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (!get_i32(env, argv[1], &n) || n <= 0) {
+        napi_throw_type_error(env, nullptr, "camshiftTrackCollect(ctx, n)");
+        return nullptr;
+    }
+    std::vector<ht_cs_trackobj> out((size_t)n);
+    ht_status st = ht_camshift_track_collect(L.ctx, n, out.data());
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_camshift_track_collect");
+    return trackobjs_result(env, out);
+}
+
+napi_value CamshiftTrackSequence(napi_env env, napi_callback_info info) {
+    size_t argc = 9;
+    napi_value argv[9];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    DevBuf *d = nullptr;
+    int32_t first = 0, n = 0, calc = 1;
+    size_t stride = 0;
+    bool out_all = false, fetch = true;
+    napi_typedarray_type t;
+    size_t ncalls;
+    void *p;
+    napi_value ab;
+    size_t off;
+    if (argc < 7 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (!get_i32(env, argv[1], &first) || !get_i32(env, argv[2], &n) || !get_i32(env, argv[3], &calc) || !get_devbuf(env, argv[4], &d)) return nullptr;
+    if (napi_get_typedarray_info(env, argv[5], &t, &ncalls, &p, &ab, &off) != napi_ok || t != napi_float64_array || ncalls == 0 || ncalls > 100000 ||
+        !get_offset(env, argv[6], &stride) || n <= 0) {
+        napi_throw_type_error(env, nullptr, "camshiftTrackSequence(ctx, first, n, calcAngles, dev, Float64Array byteOffsets, frameStride, outAll, fetch)");
+        return nullptr;
+    }
+    if (argc > 7) napi_get_value_bool(env, argv[7], &out_all);
+    if (argc > 8) napi_get_value_bool(env, argv[8], &fetch);
+    std::vector<const void *> ptrs(ncalls);
+    for (size_t k = 0; k < ncalls; k++) {
+        const double o = static_cast<const double *>(p)[k];
+        if (!(o >= 0) || (size_t)o + (size_t)n * stride > d->bytes) {
+            napi_throw_range_error(env, nullptr, "camshiftTrackSequence: a call's frames lie outside the device buffer");
+            return nullptr;
+        }
+        ptrs[k] = static_cast<const char *>(d->ptr) + (size_t)o;
+    }
+    std::vector<ht_cs_trackobj> out(fetch ? (size_t)n * (out_all ? ncalls : 1) : 0);
+    ht_status st = ht_camshift_track_sequence(L.ctx, first, n, calc, ptrs.data(), (int32_t)ncalls, stride, fetch ? out.data() : nullptr, out_all ? 1 : 0);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_camshift_track_sequence");
+    if (!fetch) return nullptr;
+    return trackobjs_result(env, out);
+}
+
+napi_value CamshiftSequenceCollect(napi_env env, napi_callback_info info) {
+    size_t argc = 4;
+    napi_value argv[4];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    int32_t n = 0, ncalls = 0;
+    bool out_all = false;
+    if (argc < 3 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (!get_i32(env, argv[1], &n) || !get_i32(env, argv[2], &ncalls) || n <= 0 || ncalls <= 0) {
+        napi_throw_type_error(env, nullptr, "camshiftSequenceCollect(ctx, n, ncalls, outAll)");
+        return nullptr;
+    }
+    if (argc > 3) napi_get_value_bool(env, argv[3], &out_all);
+    std::vector<ht_cs_trackobj> out((size_t)n * (out_all ? (size_t)ncalls : 1));
+    ht_status st = ht_camshift_sequence_collect(L.ctx, n, ncalls, out_all ? 1 : 0, out.data());
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_camshift_sequence_collect");
+    return trackobjs_result(env, out);
+}
+
+napi_value ctx_counter(napi_env env, napi_callback_info info, int which) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    Locked L;
+    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    napi_value v;
+    const double x = which == 0 ? (double)ht_frames_bound(L.ctx) : which == 1 ? (double)ht_frames_enqueued(L.ctx) : (double)ht_graph_launches(L.ctx);
+    NAPI_OK(napi_create_double(env, x, &v));
+    return v;
+}
+napi_value FramesBound(napi_env env, napi_callback_info info) { return ctx_counter(env, info, 0); }
+napi_value FramesEnqueued(napi_env env, napi_callback_info info) { return ctx_counter(env, info, 1); }
+napi_value GraphLaunches(napi_env env, napi_callback_info info) { return ctx_counter(env, info, 2); }
+
 napi_value Init(napi_env env, napi_value exports) {
     struct {
         const char *name;
@@ -575,7 +997,14 @@ napi_value Init(napi_env env, napi_value exports) {
                {"detect", Detect},               {"detectAsync", DetectAsync}, {"grayscale", Grayscale},
                {"whitebalance", Whitebalance},   {"camshiftReserve", CamshiftReserve},
                {"camshiftInit", CamshiftInit},   {"camshiftTrack", CamshiftTrack}, {"info", Info},
-               {"deviceCount", DeviceCount},     {"allgatherBest", AllgatherBest}};
+               {"deviceCount", DeviceCount},     {"allgatherBest", AllgatherBest},
+               {"hostAlloc", HostAlloc},         {"deviceAlloc", DeviceAlloc}, {"deviceFree", DeviceFree}, {"deviceUpload", DeviceUpload},
+               {"upload", Upload},               {"bindDevice", BindDevice},   {"uploadAsync", UploadAsync}, {"swapFrames", SwapFrames},
+               {"detectEnqueue", DetectEnqueue}, {"detectCollect", DetectCollect}, {"collectBest", CollectBest},
+               {"detectWhitebalance", DetectWhitebalance}, {"whitebalanceBound", WhitebalanceBound},
+               {"camshiftInitBound", CamshiftInitBound}, {"camshiftTrackBound", CamshiftTrackBound}, {"camshiftTrackCollect", CamshiftTrackCollect},
+               {"camshiftTrackSequence", CamshiftTrackSequence}, {"camshiftSequenceCollect", CamshiftSequenceCollect},
+               {"framesBound", FramesBound},     {"framesEnqueued", FramesEnqueued}, {"graphLaunches", GraphLaunches}};
     for (auto &f : fns) {
         napi_value fn;
         if (napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &fn) != napi_ok) return nullptr;
@@ -588,6 +1017,10 @@ napi_value Init(napi_env env, napi_value exports) {
     napi_set_named_property(env, exports, "INPUT_GRAY_IN_R", v);
     napi_create_int32(env, HT_INPUT_RGBA, &v);
     napi_set_named_property(env, exports, "INPUT_RGBA", v);
+    napi_create_int32(env, HT_DETECT_WHITEBALANCE, &v);
+    napi_set_named_property(env, exports, "DETECT_WHITEBALANCE", v);
+    napi_create_int32(env, HT_SCAN_STATS, &v);
+    napi_set_named_property(env, exports, "SCAN_STATS", v);
     return exports;
 }
 

@@ -15,7 +15,11 @@
  *   facetrackr.Tracker / TrackObj                       facetrackr.js:37-255  (state machine WB -> VJ -> CS)
  *   getWhitebalance(canvas)                             whitebalance.js:5-30 -> ht_whitebalance_batch
  * plus batch entry points that the single-frame browser API has no room for:
- *   detect_objects_batch(frames, w, h, cascade, interval, min_neighbors)  -> Promise<Array<Array<rect>>>
+ *   ccv.detect_objects_batch(frames, n, w, h, cascade, interval, min_neighbors, opts)  -> Promise<Array<Array<rect>>>
+ *   new ccv.DeviceBatch(w, h, n, opts)   frames resident in HBM, detect batches pipelined over several contexts (enqueue /
+ *                                        collect-best / re-enqueue), fused whitebalance, camshift call sequences — the JS form
+ *                                        of the loop bench.py times; every C-ABI export has a JS name (INTEGRATION.md)
+ *   hostAlloc(bytes)                     pinned host memory for frames that cross PCIe every call
  *
  * "canvas" is anything with width, height and getContext('2d') -> {getImageData, putImageData, drawImage,
  * createImageData}; ./canvas.js provides one for Node.  Failure conventions are the reference's: empty arrays,
@@ -93,8 +97,21 @@ function ensureGeometry(c, w, h, batch, cascade, interval) {
   if (c.w !== w || c.h !== h || c.batch < batch) {
     addon().setGeometry(c.handle, w, h, batch, levelDims(w, h, cascade, interval));
     c.w = w; c.h = h; c.batch = batch;
+    c.boundImg = null;
   }
 }
+
+/* One frame, several consumers: facetrackr.Tracker.track() reads its canvas once and the state machine may run more than one
+ * device routine on that frame (VJ detection followed by camshift.initTracker, facetrackr.js:97-108).  The ImageData object is
+ * uploaded once (ht_upload_frames) and stays bound; the *Bound addon entry points then work on it.  Every other entry point that
+ * binds frames of its own drops the marker. */
+function bindFrame(c, img, cascade, interval) {
+  if (c.boundImg === img) return;
+  ensureGeometry(c, img.width, img.height, 1, cascade, interval);
+  addon().upload(c.handle, img.data, 1, img.width, img.height);
+  c.boundImg = img;
+}
+headtrackr.hostAlloc = function (bytes) { return addon().hostAlloc(bytes); }; /* Uint8Array over pinned host memory */
 
 /* ---- ccv ------------------------------------------------------------------------------------------------------------ */
 
@@ -106,6 +123,7 @@ headtrackr.ccv.grayscale = function (canvas) { /* ccv.js:22-32, in place, return
   if (canvas.width > 0 && canvas.height > 0) {
     const c = contextFor(headtrackr.cascade, 5);
     addon().grayscale(c.handle, img.data, 1, canvas.width, canvas.height);
+    c.boundImg = null;
   }
   ctx.putImageData(img, 0, 0);
   return canvas;
@@ -213,6 +231,7 @@ headtrackr.ccv.detect_objects = function (canvas, cascade, interval, min_neighbo
   const c = contextFor(cascade, interval);
   ensureGeometry(c, w, h, 1, cascade, interval);
   const hits = addon().detect(c.handle, img.data, 1, w, h, addon().INPUT_GRAY_IN_R);
+  c.boundImg = null;
   return groupSeq(hitsToSeq(hits, 0, hits.sum.length, cascade, interval), min_neighbors);
 };
 
@@ -222,8 +241,18 @@ headtrackr.ccv.detect_objects_rgba = function (rgba, w, h, cascade, interval, mi
   const c = contextFor(cascade, interval);
   ensureGeometry(c, w, h, 1, cascade, interval);
   const hits = addon().detect(c.handle, rgba, 1, w, h, addon().INPUT_RGBA);
+  c.boundImg = null;
   return groupSeq(hitsToSeq(hits, 0, hits.sum.length, cascade, interval), min_neighbors);
 };
+
+/* the same on an ImageData that bindFrame() has (or will have) put on the device: no second upload (facetrackr's VJ step) */
+function detectBoundImg(img, cascade, interval, min_neighbors) {
+  const c = contextFor(cascade, interval);
+  bindFrame(c, img, cascade, interval);
+  addon().detectEnqueue(c.handle, addon().INPUT_RGBA);
+  const hits = addon().detectCollect(c.handle);
+  return groupSeq(hitsToSeq(hits, 0, hits.sum.length, cascade, interval), min_neighbors);
+}
 
 /* contiguous block of frames owned by `rank` (sizes differ by at most one) — the sharding of BASELINE.json configs[3] */
 function shardRange(total, rank, world) {
@@ -257,6 +286,7 @@ headtrackr.ccv.detect_objects_batch = function (frames, n, w, h, cascade, interv
     const span = shardRange(n, r, world), cnt = span[1] - span[0];
     const c = contextFor(cascade, interval, devices[r]);
     ensureGeometry(c, w, h, cnt, cascade, interval);
+    c.boundImg = null;
     const view = frames.subarray(span[0] * fbytes, span[1] * fbytes);
     jobs.push(addon().detectAsync(c.handle, view, cnt, w, h, addon().INPUT_RGBA).then(function (hits) {
       const out = [];
@@ -297,12 +327,89 @@ headtrackr.ccv.detect_objects_batch = function (frames, n, w, h, cascade, interv
   });
 };
 
+/* ---- device-resident batches: the pipelined path -------------------------------------------------------------------------
+ * new ccv.DeviceBatch(w, h, n, {cascade, interval, device, depth, sets}):
+ *   `sets` frame sets of n RGBA frames each live in ONE device buffer (HBM); `depth` native contexts (own HIP streams, own pyramid
+ *   arenas) take detect batches in turn so that `depth` batches are in flight while the host groups the previous one
+ *   (ht_detect_enqueue + ht_detect_collect_best_requeue: the C2 / C4 loop of bench.py, from JavaScript).
+ *     upload(frames, set = 0)              host -> HBM once (frames: Uint8Array of n*w*h*4 bytes)
+ *     detectBest(batches, min_neighbors, set, flags) -> {best: Float64Array(6 n) [x,y,width,height,confidence,neighbors] of the
+ *                                           last batch, hits, batches}; neighbors 0 / confidence -10000 = no face (facetrackr.js:239)
+ *     detect(min_neighbors, set)           -> Array<Array<rect>>: exactly ccv.detect_objects' result per frame (parity path)
+ *     whitebalance(set)                    -> Float64Array(n): getWhitebalance per frame, fused into a detect batch's gray pass
+ *     initTrackers(rects, set) / trackSequence(sets[], calcAngles, outAll) -> Float64Array(9 n [* calls]): n camshift streams,
+ *                                           one track() per listed frame set, ONE host call (ht_camshift_track_sequence)
+ *     destroy() */
+headtrackr.ccv.DeviceBatch = function (w, h, n, opts) {
+  opts = opts || {};
+  const cascade = opts.cascade || headtrackr.cascade, interval = opts.interval === undefined ? 5 : opts.interval;
+  const device = opts.device === undefined ? (headtrackr.device | 0) : opts.device;
+  const depth = Math.max(1, opts.depth || 3), sets = Math.max(1, opts.sets || 1);
+  const A = addon(), fbytes = w * h * 4, setBytes = n * fbytes;
+  const blob = pack.packCascade(cascade), dims = levelDims(w, h, cascade, interval);
+  const ctxs = [];
+  for (let i = 0; i < depth; i++) {
+    const hnd = A.createContext({ cascade: blob, interval: interval, device: device });
+    A.setGeometry(hnd, w, h, n, dims);
+    ctxs.push(hnd);
+  }
+  const dev = A.deviceAlloc(ctxs[0], sets * setBytes);
+  let bound = -1, trackers = false;
+  const bind = function (set) { if (bound !== set) { ctxs.forEach(function (c) { A.bindDevice(c, dev, set * setBytes, n, fbytes); }); bound = set; } };
+  this.width = w; this.height = h; this.frames = n; this.depth = depth;
+  this.upload = function (frames, set) {
+    if (frames.length < setBytes) throw new RangeError('DeviceBatch.upload: need n*w*h*4 bytes');
+    A.deviceUpload(ctxs[0], dev, (set || 0) * setBytes, frames.subarray(0, setBytes));
+  };
+  this.detectBest = function (batches, min_neighbors, set, flags) {
+    bind(set || 0);
+    flags = flags === undefined ? A.INPUT_RGBA : flags;
+    min_neighbors = min_neighbors === undefined ? 1 : min_neighbors;
+    let started = Math.min(depth, batches), r = null;
+    for (let i = 0; i < started; i++) A.detectEnqueue(ctxs[i], flags);
+    for (let i = 0; i < batches; i++) { /* collect batch i; its context re-enqueues inside the call while batches remain */
+      const more = started < batches;
+      r = A.collectBest(ctxs[i % depth], min_neighbors, more ? flags : -1);
+      if (more) started++;
+    }
+    r.batches = batches;
+    return r;
+  };
+  this.detect = function (min_neighbors, set) {
+    bind(set || 0);
+    A.detectEnqueue(ctxs[0], A.INPUT_RGBA);
+    const hits = A.detectCollect(ctxs[0]), out = [];
+    let k = 0;
+    for (let f = 0; f < n; f++) { out.push(groupSeq(hitsToSeq(hits, k, k + hits.counts[f], cascade, interval), min_neighbors)); k += hits.counts[f]; }
+    return out;
+  };
+  this.whitebalance = function (set) {
+    bind(set || 0);
+    A.detectEnqueue(ctxs[0], A.INPUT_RGBA | A.DETECT_WHITEBALANCE);
+    A.collectBest(ctxs[0], 1, -1);
+    return A.detectWhitebalance(ctxs[0], n);
+  };
+  this.initTrackers = function (rects, set) { /* rects: Int32Array [x, y, width, height] per stream (camshift.js:198-211) */
+    bind(set || 0);
+    if (!trackers) { A.camshiftReserve(ctxs[0], n); trackers = true; }
+    A.camshiftInitBound(ctxs[0], n, 0, rects);
+  };
+  this.trackSequence = function (setList, calcAngles, outAll) {
+    const offs = new Float64Array(setList.length);
+    for (let k = 0; k < setList.length; k++) offs[k] = setList[k] * setBytes;
+    return A.camshiftTrackSequence(ctxs[0], 0, n, calcAngles ? 1 : 0, dev, offs, fbytes, !!outAll, true);
+  };
+  this.graphLaunches = function () { return ctxs.reduce(function (s, c) { return s + A.graphLaunches(c); }, 0); };
+  this.destroy = function () { A.deviceFree(ctxs[0], dev); ctxs.forEach(function (c) { A.destroy(c); }); ctxs.length = 0; };
+};
+
 /* ---- whitebalance ----------------------------------------------------------------------------------------------------- */
 
 headtrackr.getWhitebalance = function (canvas) { /* whitebalance.js:5-30 */
   const img = canvas.getContext('2d').getImageData(0, 0, canvas.width, canvas.height);
   if (!(img.width > 0 && img.height > 0)) return NaN; /* 0/0 in the reference */
   const c = contextFor(headtrackr.cascade, 5);
+  c.boundImg = null;
   return addon().whitebalance(c.handle, img.data, 1, img.width, img.height)[0];
 };
 
@@ -374,23 +481,34 @@ headtrackr.camshift.Tracker = function (params) { /* camshift.js:148-354 */
   this.getSearchWindow = function () { return searchWindow.clone(); };
   this.getTrackObj = function () { return trackObj.clone(); };
 
-  this.initTracker = function (canvas, trackedArea) { /* camshift.js:198-211 */
-    canvasCtx = canvas.getContext('2d');
-    const img = canvasCtx.getImageData(0, 0, canvas.width, canvas.height);
+  /* the work of initTracker / track on an ImageData; the frame is uploaded unless the caller already has (bindFrame) */
+  this._initImg = function (img, trackedArea, ctx2d) {
+    canvasCtx = ctx2d;
     const rect = new Int32Array([trackedArea.x, trackedArea.y, trackedArea.width, trackedArea.height]);
-    addon().camshiftInit(csPool.ctx.handle, img.data, 1, canvas.width, canvas.height, slot, rect);
+    if (img.width > 0 && img.height > 0) {
+      bindFrame(csPool.ctx, img, headtrackr.cascade, 5);
+      addon().camshiftInitBound(csPool.ctx.handle, 1, slot, rect);
+    }
     modelFrame = img; modelRect = trackedArea.clone();
     searchWindow = trackedArea.clone();
     trackObj = new headtrackr.camshift.TrackObj();
   };
-
-  this.track = function (canvas) { /* camshift.js:213-259 */
-    const img = canvas.getContext('2d').getImageData(0, 0, canvas.width, canvas.height);
+  this._trackImg = function (img) {
     if (img.width === 0 || img.height === 0) return;
     lastFrame = img;
-    const r = addon().camshiftTrack(csPool.ctx.handle, img.data, 1, img.width, img.height, slot, params.calcAngles ? 1 : 0);
+    bindFrame(csPool.ctx, img, headtrackr.cascade, 5);
+    const r = addon().camshiftTrackBound(csPool.ctx.handle, 1, slot, params.calcAngles ? 1 : 0, true);
     trackObj.x = r[0]; trackObj.y = r[1]; trackObj.width = r[2]; trackObj.height = r[3]; trackObj.angle = r[4];
     searchWindow.x = r[5]; searchWindow.y = r[6]; searchWindow.width = r[7]; searchWindow.height = r[8];
+  };
+
+  this.initTracker = function (canvas, trackedArea) { /* camshift.js:198-211 */
+    const ctx2d = canvas.getContext('2d');
+    this._initImg(ctx2d.getImageData(0, 0, canvas.width, canvas.height), trackedArea, ctx2d);
+  };
+
+  this.track = function (canvas) { /* camshift.js:213-259 */
+    this._trackImg(canvas.getContext('2d').getImageData(0, 0, canvas.width, canvas.height));
   };
 
   /* debug getters: the back-projection is never materialised on the device (only these two functions can observe it),
@@ -476,10 +594,9 @@ headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
     cs = new headtrackr.camshift.Tracker({ calcAngles: params.calcAngles });
   };
 
-  function detectVJ() { /* facetrackr.js:133-182; the canvas copy + grayscale are fused into the device path */
+  function detectVJ(img) { /* facetrackr.js:133-182; the canvas copy + grayscale are fused into the device path */
     const start = now();
-    const img = input.getContext('2d').getImageData(0, 0, input.width, input.height);
-    const comp = headtrackr.ccv.detect_objects_rgba(img.data, input.width, input.height, headtrackr.cascade, 5, 1);
+    const comp = (img.width > 0 && img.height > 0) ? detectBoundImg(img, headtrackr.cascade, 5, 1) : [];
     const diff = now() - start;
     let best;
     for (let i = 0; i < comp.length; i++) if (best === undefined || comp[i].confidence > best.confidence) best = comp[i];
@@ -492,9 +609,9 @@ headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
     return result;
   }
 
-  function detectCS() { /* facetrackr.js:185-217 */
+  function detectCS(img) { /* facetrackr.js:185-217 */
     const start = now();
-    cs.track(input);
+    cs._trackImg(img);
     const r = cs.getTrackObj();
     if (params.debug) params.debug.getContext('2d').putImageData(cs.getBackProjectionImg(), 0, 0);
     const result = new headtrackr.facetrackr.TrackObj();
@@ -505,18 +622,27 @@ headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
     return result;
   }
 
-  function checkWB() { /* facetrackr.js:220-227 */
+  function checkWB(img) { /* facetrackr.js:220-227 */
     const result = new headtrackr.facetrackr.TrackObj();
-    result.wb = headtrackr.getWhitebalance(input);
+    if (img.width > 0 && img.height > 0) {
+      const c = contextFor(headtrackr.cascade, 5);
+      bindFrame(c, img, headtrackr.cascade, 5);
+      result.wb = addon().whitebalanceBound(c.handle, 1)[0];
+    } else result.wb = NaN; /* 0/0 in the reference */
     result.detection = 'WB';
     return result;
   }
 
   this.track = function () { /* facetrackr.js:67-126 */
+    /* the frame is read from the canvas and uploaded ONCE per call; whatever runs on it (whitebalance, detection, initTracker,
+     * track) shares that copy — the reference calls getImageData in each of them (whitebalance.js:12, facetrackr.js:143-149,
+     * camshift.js:206,218), here that would be one PCIe transfer each */
+    const ctx2d = input.getContext('2d');
+    const img = ctx2d.getImageData(0, 0, input.width, input.height);
     let result;
-    if (state === 'WB') result = checkWB();
-    else if (state === 'VJ') result = detectVJ();
-    else result = detectCS();
+    if (state === 'WB') result = checkWB(img);
+    else if (state === 'VJ') result = detectVJ(img);
+    else result = detectCS(img);
 
     if (result.detection === 'WB') { /* facetrackr.js:79-95 */
       if (wbWindow.length >= wbLength) wbWindow.pop();
@@ -525,8 +651,8 @@ headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
     }
     if (result.detection === 'VJ' && result.confidence > confidenceThreshold) { /* facetrackr.js:97-108 */
       state = 'CS';
-      cs.initTracker(input, new headtrackr.camshift.Rectangle(Math.floor(result.x), Math.floor(result.y),
-        Math.floor(result.width), Math.floor(result.height)));
+      cs._initImg(img, new headtrackr.camshift.Rectangle(Math.floor(result.x), Math.floor(result.y),
+        Math.floor(result.width), Math.floor(result.height)), ctx2d);
     }
     current = result;
     if (result.detection === 'CS' && params.sendEvents) { /* facetrackr.js:112-125 */

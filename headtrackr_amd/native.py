@@ -59,7 +59,7 @@ class PlaneInfo(C.Structure):
 # every symbol include/headtrackr_hip.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
     "ht_create", "ht_destroy", "ht_last_error", "ht_abi_version", "ht_set_geometry", "ht_num_levels", "ht_plane",
-    "ht_windows_per_frame", "ht_pyramid_bytes_per_frame", "ht_upload_frames", "ht_upload_frames_async", "ht_swap_frames", "ht_bind_frames_device", "ht_detect_enqueue",
+    "ht_windows_per_frame", "ht_pyramid_bytes_per_frame", "ht_upload_frames", "ht_upload_frames_async", "ht_swap_frames", "ht_bind_frames_device", "ht_frames_bound", "ht_frames_enqueued", "ht_host_alloc", "ht_host_free", "ht_device_alloc", "ht_device_free", "ht_device_upload", "ht_detect_enqueue",
     "ht_detect_collect", "ht_detect_batch", "ht_pyramid_readback", "ht_stage_counts", "ht_grayscale_batch",
     "ht_whitebalance_batch", "ht_detect_whitebalance", "ht_hits_to_rects", "ht_group_rects", "ht_best_faces", "ht_detect_collect_best", "ht_detect_collect_best_requeue", "ht_camshift_reserve", "ht_camshift_init_batch",
     "ht_camshift_track_batch", "ht_camshift_track_collect", "ht_camshift_track_sequence", "ht_camshift_sequence_collect", "ht_camshift_stats", "ht_camshift_debug_hist", "ht_allgather_records", "ht_allgather_best_faces", "ht_device_count", "ht_profile", "ht_kernel_times", "ht_stream", "ht_graph_launches", "ht_synchronize",
@@ -102,6 +102,20 @@ def lib():
     L.ht_swap_frames.argtypes = [vp]
     L.ht_bind_frames_device.restype = i32
     L.ht_bind_frames_device.argtypes = [vp, vp, i32, sz]
+    L.ht_frames_bound.restype = i32
+    L.ht_frames_bound.argtypes = [vp]
+    L.ht_frames_enqueued.restype = i32
+    L.ht_frames_enqueued.argtypes = [vp]
+    L.ht_host_alloc.restype = i32
+    L.ht_host_alloc.argtypes = [sz, C.POINTER(vp)]
+    L.ht_host_free.restype = None
+    L.ht_host_free.argtypes = [vp]
+    L.ht_device_alloc.restype = i32
+    L.ht_device_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.ht_device_free.restype = i32
+    L.ht_device_free.argtypes = [vp, vp]
+    L.ht_device_upload.restype = i32
+    L.ht_device_upload.argtypes = [vp, vp, vp, sz]
     L.ht_detect_enqueue.restype = i32
     L.ht_detect_enqueue.argtypes = [vp, u32]
     L.ht_detect_collect.restype = i32

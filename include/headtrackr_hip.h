@@ -136,6 +136,20 @@ ht_status ht_swap_frames(ht_ctx *ctx);
 /* Uses frames already resident in device memory (no copy; must stay valid until the results were collected). */
 ht_status ht_bind_frames_device(ht_ctx *ctx, const void *dev_rgba, int32_t n, size_t frame_stride);
 
+/* Frames currently bound (ht_upload_frames / ht_swap_frames / ht_bind_frames_device) and frames of the batch enqueued last: the
+ * collect calls report on the ENQUEUED batch — size counts[] / best[] with ht_frames_enqueued, not with what is bound by then. */
+int32_t ht_frames_bound(const ht_ctx *ctx);
+int32_t ht_frames_enqueued(const ht_ctx *ctx);
+
+/* Memory for hosts that have no HIP binding of their own (the Node addon): pinned host buffers — frames in them cross PCIe at link
+ * speed and may be handed to ht_upload_frames_async — and device buffers for frames that stay resident in HBM across calls
+ * (ht_bind_frames_device, ht_camshift_track_sequence).  ht_device_upload copies host -> device and returns when src may be reused. */
+ht_status ht_host_alloc(size_t bytes, void **out);
+void ht_host_free(void *p);
+ht_status ht_device_alloc(ht_ctx *ctx, size_t bytes, void **out);
+ht_status ht_device_free(ht_ctx *ctx, void *p);
+ht_status ht_device_upload(ht_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+
 /* ---- detect: ccv.grayscale + ccv.detect_objects (ccv.js:22-32, 109-246) ---------------------------------- */
 
 /* Enqueues gray -> pyramid -> cascade scan for the bound frames on the stream and returns immediately. */

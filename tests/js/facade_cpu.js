@@ -62,6 +62,14 @@ try {
   ['createContext', 'detect', 'detectAsync', 'grayscale', 'whitebalance', 'camshiftInit', 'camshiftTrack', 'deviceCount', 'allgatherBest'].forEach(function (k) {
     check(typeof addon[k] === 'function', 'addon.' + k);
   });
+  /* the pipelined path: every C-ABI export the throughput numbers are made of has a JS name (INTEGRATION.md lists the pairs) */
+  ['hostAlloc', 'deviceAlloc', 'deviceFree', 'deviceUpload', 'upload', 'bindDevice', 'uploadAsync', 'swapFrames', 'detectEnqueue', 'detectCollect', 'collectBest',
+    'detectWhitebalance', 'whitebalanceBound', 'camshiftReserve', 'camshiftInitBound', 'camshiftTrackBound', 'camshiftTrackCollect', 'camshiftTrackSequence',
+    'camshiftSequenceCollect', 'framesBound', 'framesEnqueued', 'graphLaunches', 'setGeometry', 'info', 'destroy'].forEach(function (k) {
+    check(typeof addon[k] === 'function', 'addon.' + k);
+  });
+  check(addon.DETECT_WHITEBALANCE === 32 && addon.INPUT_GRAY_IN_R === 1, 'addon flag constants');
+  check(typeof ht.ccv.DeviceBatch === 'function' && typeof ht.hostAlloc === 'function' && typeof ht.ccv.detect_objects_batch === 'function', 'batch entry points of the facade');
   out.abi = addon.abiVersion;
 } catch (e) { check(false, 'addon load: ' + e.message); }
 console.log(JSON.stringify(out));

@@ -210,5 +210,77 @@ job.facetrackr.forEach(function (cs) {
         res.best[i].neighbors === b.neighbors, 'gathered best of frame ' + i);
     }
   }
+  /* ---- the pipelined path from Node (DeviceBatch: frames resident in HBM; detectEnqueue / collectBest(requeue) over several
+   * contexts; whitebalance fused into the gray pass; camshift call sequences) against the same golden vectors --------------- */
+  if (job.detect.length) {
+    const same = job.detect.filter(function (c) { return c.w === 320 && c.h === 240 && c.interval === 5 && c.golden.min_neighbors === 1; });
+    const n = same.length, fb = 320 * 240 * 4, buf = new Uint8Array(n * fb);
+    same.forEach(function (c, i) { buf.set(fs.readFileSync(path.resolve(base, c.frame)), i * fb); });
+    const b = new headtrackr.ccv.DeviceBatch(320, 240, n, { depth: 3 });
+    b.upload(buf);
+    const lists = b.detect(1);
+    same.forEach(function (c, i) {
+      const gg = c.golden.grouped;
+      check(lists[i].length === gg.length, 'DeviceBatch.detect ' + c.name + ': grouped count');
+      for (let k = 0; k < Math.min(lists[i].length, gg.length); k++) {
+        ['x', 'y', 'width', 'height', 'confidence', 'neighbors'].forEach(function (q) { check(lists[i][k][q] === gg[k][q], 'DeviceBatch.detect ' + c.name + ': grouped[' + k + '].' + q); });
+      }
+    });
+    const r = b.detectBest(7, 1); /* 7 batches over 3 contexts: enqueue x3, then collect + re-enqueue, the last ones only collected */
+    check(r.best.length === 6 * n && r.batches === 7, 'DeviceBatch.detectBest: result shape');
+    same.forEach(function (c, i) {
+      let bb; /* facetrackr's choice (facetrackr.js:157-165) among the golden grouped rects */
+      c.golden.grouped.forEach(function (g) { if (bb === undefined || g.confidence > bb.confidence) bb = g; });
+      const o = 6 * i;
+      if (bb === undefined) check(r.best[o + 5] === 0 && r.best[o + 4] === -10000, 'DeviceBatch.detectBest ' + c.name + ': no face');
+      else check(r.best[o] === bb.x && r.best[o + 1] === bb.y && r.best[o + 2] === bb.width && r.best[o + 3] === bb.height && r.best[o + 4] === bb.confidence && r.best[o + 5] === bb.neighbors,
+        'DeviceBatch.detectBest ' + c.name + ': best face');
+    });
+    const wb = b.whitebalance();
+    same.forEach(function (c, i) { check(wb[i] === c.golden.whitebalance, 'DeviceBatch.whitebalance ' + c.name); });
+    b.destroy();
+  }
+  job.camshift.forEach(function (cs) { /* one stream, one frame set per distinct frame, every golden call in ONE trackSequence */
+    const g = cs.golden;
+    const b = new headtrackr.ccv.DeviceBatch(cs.w, cs.h, 1, { depth: 1, sets: cs.frames.length });
+    cs.frames.forEach(function (f, k) { b.upload(new Uint8Array(fs.readFileSync(path.resolve(base, f))), k); });
+    b.initTrackers(new Int32Array(g.rect), 0);
+    const r = b.trackSequence(g.calls.map(function (c) { return c.frame; }), g.calcAngles, true);
+    check(r.length === 9 * g.calls.length, cs.name + ' (sequence): result shape');
+    g.calls.forEach(function (call, i) {
+      const o = 9 * i;
+      check(r[o] === call.x && r[o + 1] === call.y && r[o + 2] === call.width && r[o + 3] === call.height, cs.name + ' (sequence) call ' + i + ': track object');
+      check(r[o + 5] === call.sw[0] && r[o + 6] === call.sw[1] && r[o + 7] === call.sw[2] && r[o + 8] === call.sw[3], cs.name + ' (sequence) call ' + i + ': search window');
+      if (call.angle === null) check(Number.isNaN(r[o + 4]), cs.name + ' (sequence) call ' + i + ': NaN angle');
+      else { let d = Math.abs(r[o + 4] - call.angle); d = Math.min(d, Math.abs(d - Math.PI)); check(d <= 1e-6, cs.name + ' (sequence) call ' + i + ': angle'); }
+    });
+    b.destroy();
+  });
+  { /* double-buffered ingest from pinned memory: uploadAsync + swapFrames under a running detect == the plain call */
+    const c0 = job.detect.find(function (c) { return c.w === 320 && c.h === 240 && c.interval === 5 && c.golden.grouped.length > 0; });
+    if (c0) {
+      const A = require(path.join(root, 'headtrackr_amd', 'js', 'headtrackr_hip.node'));
+      const pin = headtrackr.hostAlloc(2 * 320 * 240 * 4);
+      const f0 = fs.readFileSync(path.resolve(base, c0.frame));
+      pin.set(f0, 0); pin.fill(110, 320 * 240 * 4); /* frame 1: flat gray, no face */
+      const pk = require(path.join(root, 'headtrackr_amd', 'js', 'cascade_pack.js'));
+      const hnd = A.createContext({ cascade: pk.packCascade(headtrackr.cascade), interval: 5, device: 0 });
+      A.setGeometry(hnd, 320, 240, 1, null);
+      A.uploadAsync(hnd, pin.subarray(0, 320 * 240 * 4), 1); A.swapFrames(hnd);
+      A.detectEnqueue(hnd, A.INPUT_RGBA);
+      A.uploadAsync(hnd, pin.subarray(320 * 240 * 4), 1); /* next frame crosses PCIe while frame 0 is scanned */
+      const r0 = A.collectBest(hnd, 1, -1);
+      A.swapFrames(hnd);
+      A.detectEnqueue(hnd, A.INPUT_RGBA);
+      const r1 = A.collectBest(hnd, 1, -1);
+      let bb;
+      c0.golden.grouped.forEach(function (g) { if (bb === undefined || g.confidence > bb.confidence) bb = g; });
+      check(r0.best[0] === bb.x && r0.best[4] === bb.confidence && r0.best[5] === bb.neighbors, 'uploadAsync/swapFrames: frame 0 best face');
+      check(r1.best[5] === 0 && r1.hits === 0, 'uploadAsync/swapFrames: frame 1 has no face');
+      check(A.framesBound(hnd) === 1 && A.framesEnqueued(hnd) === 0, 'framesBound / framesEnqueued');
+      A.destroy(hnd);
+    }
+  }
+  out.cs_parity = (out.cs_exact || 0) + '/' + (out.cs_total || 0);
   console.log(JSON.stringify(out));
 })().catch(function (e) { out.ok = false; out.errors.push('exception: ' + e.stack); console.log(JSON.stringify(out)); });

@@ -78,3 +78,39 @@ def test_two_rank_allgather_equals_single_process():
     ret = mgr.dict()
     mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
     assert ret[0] and ret[1]
+
+
+def _bench(args, env_extra, timeout=180):
+    import json
+    import subprocess
+
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_gpus_n_launches_n_ranks():
+    """`python bench.py --gpus 2` — the one command the driver uses — must start 2 ranks itself: launcher -> torch.distributed.run ->
+    rank environment -> barriers / max over ranks -> all-gather of the best-face records (verified) -> ONE line with n_gpus 2.
+    HT_BENCH_STUB=1 swaps RCCL for gloo and the detect step for a stand-in, so the plumbing runs without GPUs."""
+    r, line = _bench(["--gpus", "2", "--steps", "4", "--warmup", "1"], {"HT_BENCH_STUB": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["launched_by_bench"] is True
+    assert line["allgather_verified"] is True and line["steps"] == 4 and line["rounds"] >= 3
+    assert line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
+    assert line["config"]["frames_total"] == 2 * line["config"]["frames_per_gpu"]
+
+
+def test_bench_refuses_to_mislabel_the_gpu_count():
+    """fewer GPUs than --gpus (here: none) is an error, not a silent 1-GPU run labelled n_gpus 1; so is a launcher whose
+    WORLD_SIZE disagrees with --gpus"""
+    r, line = _bench(["--gpus", "2", "--steps", "2"], {"HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
+    assert r.returncode != 0 and line is None and "--gpus 2" in r.stderr and "visible" in r.stderr
+    env = dict(os.environ, HT_BENCH_STUB="1", WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    import subprocess
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

@@ -76,3 +76,28 @@ def test_js_host_parity_on_gpu(tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"], out["errors"]
     assert out["checked"] > 500
+    exact, total = (int(v) for v in out["cs_parity"].split("/"))
+    assert total > 0 and exact == total, f"camshift from JS: {out['cs_parity']} calls bit-exact"
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_js_host_benchmark_runs(tmp_path):
+    """tests/js/bench_host.js (the js_host sub-record of bench.py): both detect paths and the drop-in tracker latency produce numbers,
+    the pipelined DeviceBatch path is faster than the host-frames path, and the drop-in tracker ends where the reference JS ends."""
+    import numpy as np
+
+    _build()
+    W, H, n, nt = 320, 240, 64, 30
+    c2, tr = tmp_path / "c2.raw", tmp_path / "track.raw"
+    synth.mixed_batch(n, W, H, seed0=1234).tofile(str(c2))
+    np.stack([synth.face_frame(W, H, [(90 + 2 * k, 50 + k, 96)]) for k in range(nt)]).tofile(str(tr))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "bench_host.js"), "0.4", str(c2), str(n), str(tr), str(nt)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["batch_host"]["frames_per_s"] > 0 and out["batch_device"]["frames_per_s"] > out["batch_host"]["frames_per_s"]
+    assert out["batch_device"]["frames_with_faces"] == out["batch_host"]["frames_with_faces"] > 0
+    t = out["tracker"]
+    assert t["vj_calls"] >= 4 and t["cs_calls"] >= 100 and t["last"][4] == "CS"
+    if "tracker_reference_js" in out:  # only where oracle/_ref was built (it travels with the snapshot)
+        assert out["tracker"]["same_result_as_reference"] is True, (out["tracker"]["after_60_calls"], out["tracker_reference_js"]["after_60_calls"])

@@ -111,6 +111,45 @@ __global__ __launch_bounds__(INIT_NT) void k_cs_init(const uint8_t *__restrict__
     }
 }
 
+// initTracker for a FEW streams with large rects (a live 1080p feed: 360 x 360 = 0.5 MB took the single workgroup above 54 us):
+// grid (G, streams), workgroup g takes rows g*4 + wavefront, + 4 G, ...; LDS histogram per workgroup, non-zero bins added to the
+// model (zeroed by the host) with global atomics — integer counts, any order gives the same model.
+__global__ __launch_bounds__(256) void k_cs_init_rows(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H,
+                                                      const ht_cs_rect *__restrict__ rects, HtCsState *__restrict__ states, int first) {
+    __shared__ uint32_t h[4096];
+    const int s = blockIdx.y, g = blockIdx.x, G = gridDim.x;
+    for (int i = threadIdx.x; i < 4096; i += 256) h[i] = 0;
+    __syncthreads();
+    const ht_cs_rect r = rects[s];
+    const uint32_t *img = reinterpret_cast<const uint32_t *>(frames + (size_t)s * frame_stride);
+    const int rw = max(r.width, 0), rh = max(r.height, 0);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = g * 4 + wave; j - wave < rh + 3; j += 4 * G) {  // same trip count for the four wavefronts of a workgroup
+        const int y = r.y + j;
+        for (int cb = 0; cb < rw; cb += 256) {
+            uint32_t px[4];
+            bool in[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int c = cb + 64 * u + lane, x = r.x + c;
+                in[u] = c < rw && j < rh;
+                px[u] = (in[u] && x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0u;  // outside the canvas: transparent black (camshift.js:206)
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) hist_add_wave(h, cs_bin(px[u]), 1u, in[u]);
+        }
+    }
+    __syncthreads();
+    HtCsState &st = states[first + s];
+    for (int i = threadIdx.x; i < 4096; i += 256)
+        if (h[i]) atomicAdd(&st.model[i], h[i]);
+    if (g == 0 && threadIdx.x == 0) {
+        st.sw[0] = r.x, st.sw[1] = r.y, st.sw[2] = r.width, st.sw[3] = r.height;  // camshift.js:209
+        st.x = st.y = st.width = st.height = st.angle = 0.0;                         // camshift.js:210
+        st.win_px = st.calls = 0;
+    }
+}
+
 // full-frame histogram (camshift.js:268): grid (chunks, streams) -> hist[stream][chunk][4096] partial histograms.
 // 4 pixels per 16-byte load.  LDS atomics on one address serialise lane by lane, and flat image regions put whole
 // wavefronts into one bin (a flat 320x240 background cost 64 cycles per wave instruction: the kernel ran at a quarter of
@@ -841,7 +880,16 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
     HT_HIP(c, hipMemcpyAsync(d_rects, rects, sizeof(ht_cs_rect) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     {
         HtProfScope ps(c, "cs_init");
-        hipLaunchKernelGGL(k_cs_init, dim3(n), dim3(INIT_NT), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, d_rects, c->d_cs, first);
+        // few streams with tall rects: rows spread over G workgroups per stream (one workgroup per stream would leave the chip idle)
+        int max_rh = 0;
+        for (int i = 0; i < n; i++) max_rh = std::max(max_rh, rects[i].height);
+        const int G = std::min(std::min(32, std::max(1, c->num_cus * 2 / std::max(n, 1))), (max_rh + 15) / 16);
+        if (n < 64 && G >= 2) {
+            HT_HIP(c, hipMemset2DAsync(c->d_cs[first].model, sizeof(HtCsState), 0, sizeof(uint32_t) * 4096, (size_t)n, c->stream));
+            hipLaunchKernelGGL(k_cs_init_rows, dim3(G, n), dim3(256), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, d_rects, c->d_cs, first);
+        } else {
+            hipLaunchKernelGGL(k_cs_init, dim3(n), dim3(INIT_NT), 0, c->stream, c->d_frames, c->frame_stride, c->W, c->H, d_rects, c->d_cs, first);
+        }
         HT_HIP(c, hipGetLastError());
     }
     HT_HIP(c, hipStreamSynchronize(c->stream));  // rects[] is the caller's (pageable) memory

@@ -122,8 +122,33 @@ bool get_bytes(napi_env env, napi_value v, uint8_t **data, size_t *len) {
     return false;
 }
 
+// Every live Slot, so that the environment's cleanup hook can destroy the contexts while the HIP runtime is still up: finalizers
+// of externals may run during environment teardown or not at all, and a context destroyed after the runtime's own static
+// destructors crashes the process at exit.
+std::mutex g_slots_mu;
+std::vector<Slot *> g_slots;
+bool g_env_down = false;
+
+void env_cleanup(void *) {
+    std::lock_guard<std::mutex> lk(g_slots_mu);
+    g_env_down = true;
+    for (Slot *s : g_slots) {
+        std::lock_guard<std::recursive_mutex> l2(s->mu);
+        if (s->ctx) ht_destroy(s->ctx);
+        s->ctx = nullptr;
+    }
+}
+
 void finalize_ctx(napi_env, void *data, void *) {
     Slot *slot = static_cast<Slot *>(data);
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        for (size_t i = 0; i < g_slots.size(); i++)
+            if (g_slots[i] == slot) {
+                g_slots.erase(g_slots.begin() + (long)i);
+                break;
+            }
+    }
     if (slot->ctx) ht_destroy(slot->ctx);
     delete slot;
 }
@@ -167,6 +192,10 @@ napi_value CreateContext(napi_env env, napi_callback_info info) {
     if (st != HT_OK) return throw_ht(env, nullptr, st, "ht_create");
     Slot *slot = new Slot();
     slot->ctx = ctx;
+    {
+        std::lock_guard<std::mutex> lk(g_slots_mu);
+        g_slots.push_back(slot);
+    }
     napi_value ext;
     NAPI_OK(napi_create_external(env, slot, finalize_ctx, nullptr, &ext));
     return ext;
@@ -622,7 +651,7 @@ void finalize_devbuf(napi_env env, void *data, void *) {
         std::lock_guard<std::recursive_mutex> lk(d->slot->mu);
         if (d->slot->ctx) (void)ht_device_free(d->slot->ctx, d->ptr);
     }
-    if (d->ctx_ref) napi_delete_reference(env, d->ctx_ref);
+    if (d->ctx_ref && !g_env_down) napi_delete_reference(env, d->ctx_ref);
     delete d;
 }
 bool get_devbuf(napi_env env, napi_value v, DevBuf **out) {
@@ -990,6 +1019,7 @@ napi_value FramesEnqueued(napi_env env, napi_callback_info info) { return ctx_co
 napi_value GraphLaunches(napi_env env, napi_callback_info info) { return ctx_counter(env, info, 2); }
 
 napi_value Init(napi_env env, napi_value exports) {
+    napi_add_env_cleanup_hook(env, env_cleanup, nullptr);
     struct {
         const char *name;
         napi_callback fn;

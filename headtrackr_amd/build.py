@@ -29,6 +29,13 @@ for _knob in ("HT_TILE_NT", "HT_TILE_TYH", "HT_TILE_WPS", "HT_TILE_WAVEQ", "HT_T
         HIP_FLAGS.append(f"-D{_knob}=" + os.environ[_knob])
 
 
+# per-source flags.  ht_camshift.hip: MachineLICM hoists the constant tables of the once-per-call epilogue (atan2 / sqrt polynomials, 40+
+# VGPRs) out of k_cs_track_fused<true>'s call loop and the register allocator then SPILLS them (24 VGPRs, 100 B of scratch per lane) at
+# the 128-VGPR cap of a 1024-thread workgroup; without the pass the kernel needs 122 VGPRs and no scratch (tests/test_abi.py checks the
+# code object).
+EXTRA_FLAGS = {"ht_camshift.hip": ["-mllvm", "-disable-machine-licm"]}
+
+
 def _newer(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
@@ -44,7 +51,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         for s in srcs:  # the translation units are independent: compile them side by side (ht_scan.hip alone takes ~1.5 min)
             o = os.path.splitext(s)[0] + ".o"
             if force or _newer(o, deps):
-                cmd = [HIPCC, *HIP_FLAGS, "-c", s, "-o", o]
+                cmd = [HIPCC, *HIP_FLAGS, *EXTRA_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]
                 if verbose:
                     print(" ".join(cmd))
                 procs.append((cmd, subprocess.Popen(cmd)))

@@ -255,9 +255,11 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
     const int nwa = min(NW, max(4, (hh + 7) >> 3));
     if (ww > 0 && hh > 0 && wave < nwa) {
         for (int j0 = wave; j0 < hh; j0 += 8 * nwa) {
-            double rs[8], ts[8], us[8];
+            // per row: rs = sum val, ts = sum vx val (both are needed again times the row's y); the x^2 sum has no y factor and
+            // goes straight into m20 (one accumulator instead of eight: the kernel sits at the 128-VGPR cap of a 1024-thread workgroup)
+            double rs[8], ts[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) rs[r] = ts[r] = us[r] = 0.0;
+            for (int r = 0; r < 8; r++) rs[r] = ts[r] = 0.0;
             for (int cb = 0; cb < ww; cb += 64) {  // cb: wave-uniform chunk base
                 const int c = cb + lane, cc = min(c, ww - 1);
                 uint32_t px[8];
@@ -277,7 +279,7 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
                     const double vv = (colok && j0 + r * nwa < hh) ? val[r] : 0.0;
                     rs[r] += vv;
                     ts[r] += vx * vv;
-                    if (SECOND) us[r] += vx * vx * vv;
+                    if (SECOND) m.m20 += vx * vx * vv;
                 }
             }
 #pragma unroll
@@ -288,7 +290,6 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
                 m.m01 += vy * rs[r];
                 if (SECOND) {
                     m.m11 += vy * ts[r];
-                    m.m20 += us[r];
                     m.m02 += vy * vy * rs[r];
                 }
             }
@@ -307,12 +308,18 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
     CS_STAMP(fine, 3);
     __syncthreads();
     CS_STAMP(fine, 4);
+    // the workgroup's sums: lane k of EVERY wavefront adds the NW wave sums of moment k in the fixed order q = 0 .. NW-1 (the same
+    // bits in every wavefront) and the results are broadcast as wave-uniform scalars.  (Every lane used to add all 6 x NW values
+    // itself: 96 binary64 adds per thread — a quarter of a pass's VALU time, and 192 VGPRs of loads in flight that spilled.)
+    {
+        double sacc = 0.0;
+        if (lane < nv) {
 #pragma unroll
-    for (int k = 0; k < nv; k++) {
-        double s = 0.0;
+            for (int q = 0; q < NW; q++) sacc += red[lane][q];
+        }
 #pragma unroll
-        for (int q = 0; q < NW; q++) s += red[k][q];  // fixed order; all NW loads issue at once
-        v[k] = s;
+        for (int k = 0; k < nv; k++)
+            v[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), k), __builtin_amdgcn_readlane(__double2loint(sacc), k));
     }
     CS_STAMP(fine, 5);
     m.m00 = v[0], m.m10 = v[1], m.m01 = v[2], m.m11 = v[3], m.m20 = v[4], m.m02 = v[5];
@@ -330,9 +337,15 @@ __device__ __forceinline__ Mom window_moments_any(const uint32_t *__restrict__ i
 
 // Copies the neighbourhood of the search window (the window clamped to the frame, grown by as large a margin as `cap` pixels
 // allow, at most 16) into LDS as histogram bins.  All loads are independent: one round of memory latency for the whole region.
+// workgroup-uniform integers (search window, region rectangle, loop bounds) are pinned to scalar registers: every thread computes the
+// same values, but the compiler cannot know that of something read from LDS and would keep them — and the whole integer side of the
+// mean-shift loop — in VGPRs, of which this 1024-thread kernel has exactly 128
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ CsRegion cs_region_rect(int W, int H, const int *s_sw, uint16_t *bins, int cap) {
     CsRegion R = {bins, 0, 0, 0, 0};
-    const int x0 = max(s_sw[0], 0), y0 = max(s_sw[1], 0), x1 = min(x0 + s_sw[2], W), y1 = min(y0 + s_sw[3], H);
+    const int sw0 = uni(s_sw[0]), sw1 = uni(s_sw[1]), sw2 = uni(s_sw[2]), sw3 = uni(s_sw[3]);
+    const int x0 = max(sw0, 0), y0 = max(sw1, 0), x1 = min(x0 + sw2, W), y1 = min(y0 + sw3, H);
     const int w0 = x1 - x0, h0 = y1 - y0;
     if (w0 <= 0 || h0 <= 0 || (long long)w0 * h0 > cap) return R;
     int mg = 0;
@@ -365,17 +378,16 @@ __device__ __forceinline__ CsRegion cs_cache_region(const uint32_t *__restrict__
 
 // meanShift + camShift (camshift.js:222-312) once the weight LUT is in LDS; every thread runs the identical scalar logic,
 // thread 0 writes the state.  NW = wavefronts of the workgroup.
-// `moments(second, x, y, w, h)` computes camshift.Moments over the window for the whole workgroup (every thread gets the same Mom).
+// `moments(x, y, w, h)` computes camshift.Moments (all six sums) over the window for the whole workgroup (every thread gets the same Mom).
 template <typename MOMENTS>
 __device__ __forceinline__ void meanshift_body(int W, int H, const int *s_sw, HtCsState &st, int calc_angles, int max_it, ht_cs_trackobj *__restrict__ out_s,
                                                unsigned long long *stamps, bool writer, MOMENTS moments) {
-    int swx = s_sw[0], swy = s_sw[1];
+    int swx = uni(s_sw[0]), swy = uni(s_sw[1]);
     int n_stamp = 4;
     (void)n_stamp;
-    const int sww = s_sw[2], swh = s_sw[3];
+    const int sww = uni(s_sw[2]), swh = uni(s_sw[3]);
     int prevx = swx, prevy = swy;  // camshift.js:280-281
     Mom m = {0, 0, 0, 0, 0, 0};
-    bool have_second = false;
     int wadx = 0, wady = 0, wadw = 0, wadh = 0;
     unsigned long long visited = 0;  // window pixels read by the moment passes (B_track = 4*W*H + 4*sum(window))
     for (int it = 0; it < max_it; it++) {  // camshift.js:284-306; max_it = 10 (HT_DEBUG_CS_ITERS: measurement knob, wrong results)
@@ -384,25 +396,20 @@ __device__ __forceinline__ void meanshift_body(int W, int H, const int *s_sw, Ht
         wadw = min(wadx + sww, W);
         wadh = min(wady + swh, H);
         visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
-        if (it == 9) {
-            m = moments(true, wadx, wady, wadw, wadh);
-            have_second = true;
-        } else {
-            m = moments(false, wadx, wady, wadw, wadh);
-        }
+        // Every pass computes all six sums.  The reference computes the second moments only in its 10th iteration or, once the
+        // window stopped moving, in ONE MORE pass over the same window (camshift.js:299-301) — whose first-moment sums are, operation
+        // for operation, the ones this pass already has: the extra pass (a quarter of a typical call's passes) is not run.
+        m = moments(wadx, wady, wadw, wadh);
         CS_STAMP(stamps, n_stamp);
         n_stamp++;
         if (it == 0) CS_STAMP(stamps, 22);
         const double inv = 1.0 / m.m00, xc = m.m10 * inv, yc = m.m01 * inv;  // camshift.js:109-111
-        swx += toint32(xc - (double)sww / 2);                                    // camshift.js:295
-        swy += toint32(yc - (double)swh / 2);                                    // camshift.js:296
+        swx += uni(toint32(xc - (double)sww / 2));                               // camshift.js:295 (every thread holds the same sums)
+        swy += uni(toint32(yc - (double)swh / 2));                               // camshift.js:296
         if (it == 0) CS_STAMP(stamps, 23);
         if (swx == prevx && swy == prevy) {                                      // camshift.js:299-301
-            if (!have_second) {
-                m = moments(true, wadx, wady, wadw, wadh);
-                visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
-            }
-            have_second = true;
+            // `visited` keeps counting the reference's passes (B_track = 4 W H + 4 sum of the window passes)
+            if (it != 9) visited += (unsigned long long)max(wadw - wadx, 0) * (unsigned long long)max(wadh - wady, 0);
             break;
         }
         prevx = swx;
@@ -482,9 +489,8 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
     __syncthreads();
     const CsRegion R = cs_cache_region<CS_NT>(img, W, H, s_sw, reinterpret_cast<uint16_t *>(cs_dyn), region_cap);
     __syncthreads();
-    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, true, [&](bool second, int x, int y, int w, int h) {
-        return second ? window_moments_any<true, CS_NT / 64>(img, W, lut, R, x, y, w, h, red) : window_moments_any<false, CS_NT / 64>(img, W, lut, R, x, y, w, h, red);
-    });
+    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, true,
+                   [&](int x, int y, int w, int h) { return window_moments_any<true, CS_NT / 64>(img, W, lut, R, x, y, w, h, red); });
 }
 
 // One launch per track() call when there are enough streams to fill the chip by themselves: ONE 1024-thread workgroup per stream
@@ -502,22 +508,43 @@ constexpr int CS_SEQ_MAX = 64;
 struct CsFrameList {
     const uint8_t *p[CS_SEQ_MAX];
 };
-// SEQ = false: exactly one call, no loop (the loop costs the 128-VGPR kernel a few dozen spilled loop invariants and a scratch allocation)
+// Everything the kernel needs travels in ONE struct = the whole kernarg segment.  The kernel reads it through the kernarg pointer,
+// made opaque at the top of every call of the sequence: the ~20 scalars are then re-loaded (scalar loads from the constant cache) per
+// call instead of being kept alive across the whole call body — as loop invariants they cost the 128-VGPR kernel 52 spilled VGPRs and
+// 24 spilled SGPRs (212 B of scratch per lane).
+struct CsFusedArgs {
+    CsFrameList flist;
+    int ncalls;
+    int W, H;
+    uint32_t npix;
+    size_t frame_stride;
+    HtCsState *states;
+    int first, calc_angles, max_it, region_cap;
+    ht_cs_trackobj *out;
+    uint32_t *dbg_hist;
+    uint32_t out_call_stride;
+};
+typedef const CsFusedArgs __attribute__((address_space(4))) *CsFusedArgsPtr;
+
 template <bool SEQ>
-__global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFrameList flist, int ncalls_arg, size_t frame_stride, int W, int H, uint32_t npix,
-                                                            HtCsState *__restrict__ states, int first, int calc_angles, int max_it, int region_cap,
-                                                            ht_cs_trackobj *__restrict__ out, uint32_t out_call_stride, uint32_t *__restrict__ dbg_hist) {
+__global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFusedArgs args_by_value) {
     extern __shared__ __attribute__((aligned(16))) uint8_t cs_dyn[];  // [region_cap] u16 bins of the cached search region
     __shared__ double lut[4096];
     __shared__ uint32_t h[4096];
     __shared__ double red[6][FUSED_NT / 64];
     __shared__ int s_sw[4];
+    (void)args_by_value;
+    CsFusedArgsPtr ka = (CsFusedArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     const int s = blockIdx.x;
-    HtCsState &st = states[first + s];
-    const int ncalls = SEQ ? ncalls_arg : 1;
+    const int ncalls = SEQ ? ka->ncalls : 1;
     for (int call = 0; call < ncalls; call++) {
+    if (SEQ) asm volatile("" : "+s"(ka));  // opaque: nothing loaded through ka before this point stays live across the call
     if (call) __syncthreads();  // thread 0 stored the new search window; every wavefront is done with h / lut / the cached region
-    const uint8_t *frame = flist.p[call] + (size_t)s * frame_stride;
+    const int W = ka->W, H = ka->H, region_cap = ka->region_cap;
+    const uint32_t npix = ka->npix;
+    HtCsState &st = ka->states[ka->first + s];
+    const uint8_t *frame = ka->flist.p[call] + (size_t)s * ka->frame_stride;
+    uint32_t *const dbg_hist = ka->dbg_hist;
 #ifdef HT_CS_TIMELINE
     __shared__ unsigned long long s_stamps[32];
     if (threadIdx.x < 32) s_stamps[threadIdx.x] = 0;
@@ -622,9 +649,9 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFrameList f
     __syncthreads();  // LUT and region complete
     CS_STAMP(stamps, 3);
     const uint32_t *img = reinterpret_cast<const uint32_t *>(frame);
-    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + (size_t)call * out_call_stride + s : nullptr, stamps, true, [&](bool second, int x, int y, int w, int h) {
-        return second ? window_moments_any<true, FUSED_NT / 64>(img, W, lut, R, x, y, w, h, red) : window_moments_any<false, FUSED_NT / 64>(img, W, lut, R, x, y, w, h, red);
-    });
+    ht_cs_trackobj *const out = ka->out;
+    meanshift_body(W, H, s_sw, st, ka->calc_angles, ka->max_it, out ? out + (size_t)call * ka->out_call_stride + s : nullptr, stamps, true,
+                   [&](int x, int y, int w, int h) { return window_moments_any<true, FUSED_NT / 64>(img, W, lut, R, x, y, w, h, red); });
 #ifdef HT_CS_TIMELINE
     if (threadIdx.x == 0 && dbg_hist)
         for (int i = 0; i < 30; i++) reinterpret_cast<unsigned long long *>(dbg_hist + (size_t)s * 4096 + 4032)[i] = s_stamps[i];
@@ -754,11 +781,13 @@ __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img,
     __syncthreads();
     if ((int)threadIdx.x < G * 6) s_part[threadIdx.x] = __hip_atomic_load(&slot_parts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
+    {  // lane k of every wavefront adds moment k's G partials in the fixed order q = 0 .. G-1: every workgroup of the cluster gets the same bits
+        double sacc = 0.0;
+        if (lane < nv)
+            for (int q = 0; q < G; q++) sacc += s_part[q * 6 + lane];
 #pragma unroll
-    for (int k = 0; k < nv; k++) {
-        double sum = 0.0;
-        for (int q = 0; q < G; q++) sum += s_part[q * 6 + k];  // fixed order: every workgroup of the cluster gets the same bits
-        v[k] = sum;
+        for (int k = 0; k < nv; k++)
+            v[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sacc), k), __builtin_amdgcn_readlane(__double2loint(sacc), k));
     }
     m.m00 = v[0], m.m10 = v[1], m.m01 = v[2], m.m11 = v[3], m.m20 = v[4], m.m02 = v[5];
     return m;
@@ -786,10 +815,9 @@ __global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *_
     double *my_parts = parts + (size_t)s * CL_SLOTS * CL_MAXG * 6;
     const ClusterSync sync = {counters + s, err, budget, &s_timeout};
     int slot = 0;
-    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, g == 0, [&](bool second, int x, int y, int w, int h) {
+    meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, g == 0, [&](int x, int y, int w, int h) {
         const int sl = slot++;
-        return second ? cluster_moments<true>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, sync, sl)
-                      : cluster_moments<false>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, sync, sl);
+        return cluster_moments<true>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, sync, sl);
     });
 }
 
@@ -909,10 +937,13 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
     // (a handful of large feeds): chunk histograms from every CU, then one mean-shift workgroup per stream
     if (n >= c->cs_fused_min_streams) {
         HtProfScope ps(c, "cs_track");
-        CsFrameList fl;
-        fl.p[0] = frames;
-        hipLaunchKernelGGL(k_cs_track_fused<false>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, fl, 1, frame_stride, c->W, c->H, npix, c->d_cs, first,
-                           calc_angles, c->dbg_cs_iters, c->cs_region_cap, d_out, 0u, c->cs_keep_hist ? c->d_cs_hist : nullptr);
+        CsFusedArgs ka;
+        std::memset(&ka, 0, sizeof(ka));
+        ka.flist.p[0] = frames;
+        ka.ncalls = 1, ka.W = c->W, ka.H = c->H, ka.npix = npix, ka.frame_stride = frame_stride, ka.states = c->d_cs, ka.first = first;
+        ka.calc_angles = calc_angles, ka.max_it = c->dbg_cs_iters, ka.region_cap = c->cs_region_cap, ka.out = d_out, ka.out_call_stride = 0u;
+        ka.dbg_hist = c->cs_keep_hist ? c->d_cs_hist : nullptr;
+        hipLaunchKernelGGL(k_cs_track_fused<false>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, ka);
         HT_HIP(c, hipGetLastError());
         c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;
         return HT_OK;
@@ -1014,12 +1045,15 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
         const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
         for (int k0 = 0; k0 < ncalls; k0 += CS_SEQ_MAX) {
             const int kc = std::min(CS_SEQ_MAX, ncalls - k0);
-            CsFrameList fl;
-            for (int k = 0; k < kc; k++) fl.p[k] = static_cast<const uint8_t *>(dev_frames[k0 + k]);
+            CsFusedArgs ka;
+            std::memset(&ka, 0, sizeof(ka));
+            for (int k = 0; k < kc; k++) ka.flist.p[k] = static_cast<const uint8_t *>(dev_frames[k0 + k]);
+            ka.ncalls = kc, ka.W = c->W, ka.H = c->H, ka.npix = npix, ka.frame_stride = frame_stride, ka.states = c->d_cs, ka.first = first;
+            ka.calc_angles = calc_angles, ka.max_it = c->dbg_cs_iters, ka.region_cap = c->cs_region_cap;
+            ka.out = c->d_cs_seq_out + (out_all ? (size_t)k0 * n : 0), ka.out_call_stride = out_all ? (uint32_t)n : 0u;
+            ka.dbg_hist = c->cs_keep_hist ? c->d_cs_hist : nullptr;
             HtProfScope ps(c, "cs_track");
-            hipLaunchKernelGGL(k_cs_track_fused<true>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, fl, kc, frame_stride, c->W, c->H, npix, c->d_cs, first,
-                               calc_angles, c->dbg_cs_iters, c->cs_region_cap, c->d_cs_seq_out + (out_all ? (size_t)k0 * n : 0), out_all ? (uint32_t)n : 0u,
-                               c->cs_keep_hist ? c->d_cs_hist : nullptr);
+            hipLaunchKernelGGL(k_cs_track_fused<true>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, ka);
             HT_HIP(c, hipGetLastError());
         }
         c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;

@@ -332,6 +332,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_cs_parts) (void)hipFree(c->d_cs_parts);
     if (c->d_cs_ctr) (void)hipFree(c->d_cs_ctr);
     if (c->d_gather) (void)hipFree(c->d_gather);
+    for (auto &a : c->user_allocs) (void)hipFree(a.first);
     for (auto &t : c->timers)
         for (auto &p : t.pending) (void)hipEventDestroy(p.first), (void)hipEventDestroy(p.second);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -779,6 +780,7 @@ extern "C" ht_status ht_device_alloc(ht_ctx *c, size_t bytes, void **out) {
         (void)hipGetLastError();
         return ht_fail(c, HT_ERR_NOMEM, "ht_device_alloc: hipMalloc failed");
     }
+    c->user_allocs.emplace_back(*out, bytes);
     return HT_OK;
 }
 extern "C" ht_status ht_device_free(ht_ctx *c, void *p) {
@@ -786,7 +788,11 @@ extern "C" ht_status ht_device_free(ht_ctx *c, void *p) {
     if (!p) return HT_OK;
     HT_HIP(c, hipSetDevice(c->device));
     HT_HIP(c, hipStreamSynchronize(c->stream));  // nothing enqueued on this context may still read it
-    if (c->d_frames == p) c->d_frames = nullptr, c->nframes = 0;
+    auto it = std::find_if(c->user_allocs.begin(), c->user_allocs.end(), [p](const std::pair<void *, size_t> &a) { return a.first == p; });
+    if (it == c->user_allocs.end()) return ht_fail(c, HT_ERR_INVALID, "ht_device_free: not a live ht_device_alloc buffer of this context");
+    const uint8_t *pb = static_cast<const uint8_t *>(p);
+    if (c->d_frames && c->d_frames >= pb && c->d_frames < pb + it->second) c->d_frames = nullptr, c->nframes = 0;  // frames bound inside it
+    c->user_allocs.erase(it);
     HT_HIP(c, hipFree(p));
     return HT_OK;
 }

@@ -348,6 +348,8 @@ struct ht_ctx {
     int cs_region_cap = 40960;        // pixels of the LDS-cached search region (HT_DEBUG_CS_REGION=0 disables it)        // HT_DEBUG_CS_KEEP_HIST: the fused kernel also writes its histogram for ht_camshift_debug_hist
     int cs_last_first = 0, cs_last_n = 0, cs_last_chunks = 0;  // layout of d_cs_hist after the last track call (debug read-back)
 
+    std::vector<std::pair<void *, size_t>> user_allocs;  // ht_device_alloc buffers still alive (pointer, bytes): freed by ht_destroy at the latest
+
     // multi-GPU exchange buffer (ht_allgather_best_faces)
     void *d_gather = nullptr;
     size_t d_gather_bytes = 0;

@@ -33,6 +33,7 @@
 //   framesBound(ctx), framesEnqueued(ctx), graphLaunches(ctx)
 #include <node_api.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -64,6 +65,7 @@ napi_value throw_ht(napi_env env, ht_ctx *ctx, ht_status st, const char *where) 
 // takes `mu` for the duration of its C-ABI calls, so overlapping calls run one after the other, in lock-acquisition order.
 struct Slot {
     ht_ctx *ctx = nullptr;
+    std::atomic<int> refs{1};  // the context's JS handle + every device buffer allocated on it (their finalizers need the lock below)
     std::recursive_mutex mu;  // recursive: a GC finalizer (device buffers) may run on the JS thread inside an entry point that holds it
 };
 
@@ -139,8 +141,10 @@ void env_cleanup(void *) {
     }
 }
 
-void finalize_ctx(napi_env, void *data, void *) {
-    Slot *slot = static_cast<Slot *>(data);
+// Finalizers never call back into N-API: Node 12 runs pending finalizers while it tears the environment down, and napi calls made from
+// them at that point crash inside libnode (seen as a SIGSEGV at exit in GlobalHandles::InvokeSecondPassPhantomCallbacks).
+void release_slot(Slot *slot) {
+    if (slot->refs.fetch_sub(1) != 1) return;
     {
         std::lock_guard<std::mutex> lk(g_slots_mu);
         for (size_t i = 0; i < g_slots.size(); i++)
@@ -149,8 +153,17 @@ void finalize_ctx(napi_env, void *data, void *) {
                 break;
             }
     }
-    if (slot->ctx) ht_destroy(slot->ctx);
     delete slot;
+}
+
+void finalize_ctx(napi_env, void *data, void *) {
+    Slot *slot = static_cast<Slot *>(data);
+    {
+        std::lock_guard<std::recursive_mutex> lk(slot->mu);
+        if (slot->ctx) ht_destroy(slot->ctx);  // also frees the device buffers allocated on it
+        slot->ctx = nullptr;
+    }
+    release_slot(slot);
 }
 
 napi_value CreateContext(napi_env env, napi_callback_info info) {
@@ -640,24 +653,25 @@ napi_value HostAlloc(napi_env env, napi_callback_info info) {
 // a device buffer: freed explicitly (deviceFree) or, at the latest, when the JS handle is collected — through the context it was
 // allocated on, which the handle keeps alive
 struct DevBuf {
-    Slot *slot = nullptr;
+    Slot *slot = nullptr;  // holds one reference on the slot: the lock outlives the context's JS handle
     void *ptr = nullptr;
     size_t bytes = 0;
-    napi_ref ctx_ref = nullptr;
 };
-void finalize_devbuf(napi_env env, void *data, void *) {
+void finalize_devbuf(napi_env, void *data, void *) {
     DevBuf *d = static_cast<DevBuf *>(data);
-    if (d->ptr && d->slot) {
-        std::lock_guard<std::recursive_mutex> lk(d->slot->mu);
-        if (d->slot->ctx) (void)ht_device_free(d->slot->ctx, d->ptr);
+    if (d->slot) {
+        {
+            std::lock_guard<std::recursive_mutex> lk(d->slot->mu);
+            if (d->ptr && d->slot->ctx) (void)ht_device_free(d->slot->ctx, d->ptr);  // a destroyed context has freed it already
+        }
+        release_slot(d->slot);
     }
-    if (d->ctx_ref && !g_env_down) napi_delete_reference(env, d->ctx_ref);
     delete d;
 }
 bool get_devbuf(napi_env env, napi_value v, DevBuf **out) {
     void *p = nullptr;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<DevBuf *>(p)->ptr) {
-        napi_throw_type_error(env, nullptr, "expected a live device buffer (deviceAlloc)");
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<DevBuf *>(p)->ptr || !static_cast<DevBuf *>(p)->slot->ctx) {
+        napi_throw_type_error(env, nullptr, "expected a live device buffer (deviceAlloc) of a live context");
         return false;
     }
     *out = static_cast<DevBuf *>(p);
@@ -682,8 +696,8 @@ napi_value DeviceAlloc(napi_env env, napi_callback_info info) {
         return throw_ht(env, L.ctx, st, "ht_device_alloc");
     }
     get_slot(env, argv[0], &d->slot);
+    d->slot->refs.fetch_add(1);
     d->bytes = (size_t)bytes;
-    napi_create_reference(env, argv[0], 1, &d->ctx_ref);
     napi_value ext;
     NAPI_OK(napi_create_external(env, d, finalize_devbuf, nullptr, &ext));
     return ext;

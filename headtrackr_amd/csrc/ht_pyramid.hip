@@ -740,7 +740,9 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
     const size_t regular_end = c->tail_first_gen > 0 ? (size_t)c->tail_first_gen : c->h_gens.size();
     for (size_t g = 1; g < regular_end; g++) {
         if (c->gen_blocks[g] == 0) continue;
-        HtProfScope ps(c, "resample");
+        char gname[24];
+        std::snprintf(gname, sizeof(gname), "resample_g%d", (int)g);
+        HtProfScope ps(c, getenv("HT_DEBUG_RS_GENNAMES") ? gname : "resample");  // measurement knob: device time per pyramid generation
         // frames per workgroup: as many as keep >= ~4 workgroups per CU slot in the launch, at most rs_group; groups never
         // straddle the 8 XCD shares of the batch when the batch is a multiple of 8 * K
         uint32_t K = 1;
@@ -759,7 +761,7 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         }
     }
     if (c->tail_first_gen > 0) {
-        HtProfScope ps(c, "resample");
+        HtProfScope ps(c, getenv("HT_DEBUG_RS_GENNAMES") ? "resample_tail" : "resample");
         if (c->tail_table)
             hipLaunchKernelGGL(k_resample_tail, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
                                c->d_tail_tapref, c->d_tail_taps_fast, c->d_tail_taps, c->h_tail, c->d_arena, c->arena_stride, (uint32_t)c->nframes);

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 short = {"k_gray_linear": "gray", "k_resample": "resample", "k_resample_tail": "resample_tail", "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep",
          "k_scan_deep_lds": "scan_deep", "k_cs_track_fused": "cs_track", "k_cs_hist": "cs_hist", "k_cs_meanshift": "cs_meanshift", "k_cs_init": "cs_init"}
 traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/gpu_pmc.sh): bytes = "
@@ -58,6 +58,10 @@ for wl in ("c2", "c4", "c3"):
 for name in ("tile_timeline_c2.txt", "tile_timeline_c4.txt", "rs_phases_c2.txt", "rs_phases_c4.txt"):  # shader-clock phase timelines (tools/gpu_tile_timeline.py, gpu_rs_phases.py)
     src = os.path.join(G, name)
     if os.path.exists(src):
+        txt = open(src).read()
+        if "Traceback" in txt or "Error" in txt or len(txt.strip().splitlines()) < 3:  # round 2 committed tracebacks of stale builds as "timelines"
+            print(f"REFUSED {name}: not a timeline (traceback / error / empty)")
+            continue
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
 for name in ("default", "c5"):
     bj = os.path.join(G, f"bench_{name}.json")

@@ -10,7 +10,7 @@ echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --no-header 
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 t0=$(date +%s)
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default exit $? ($(( $(date +%s) - t0 )) s)"; cut -c1-300 $OUT/bench_default.json
-timeout 600 python bench.py --workload c5 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; echo "bench c5 exit $?"; cut -c1-200 $OUT/bench_c5.json
+timeout 600 python bench.py --workload c5 --feeds 8 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; echo "bench c5 exit $?"; cut -c1-200 $OUT/bench_c5.json
 if [ "${RUN_PROF:-1}" = 1 ]; then
 cd /tmp
 for wl in c2 c4 c3; do
@@ -25,10 +25,21 @@ for wl in c2 c4 c3; do
   echo "pmc $wl done"
 done
 fi
-# shader-clock phase timelines of the two big kernels (instrumented builds: alt/tltl.so = -DHT_TILE_TIMELINE, alt/rsph.so = -DHT_RS_PHASES)
+# shader-clock phase timelines of the two big kernels (instrumented builds: alt/tltl.so = -DHT_TILE_TIMELINE, alt/rsph.so = -DHT_RS_PHASES,
+# built by tools/build_alt.py from the CURRENT sources: a stale variant is refused, stderr never lands in the evidence files)
 LIB=headtrackr_amd/libheadtrackr_hip.so
 cp $LIB /tmp/final_base.so
-if [ -f alt/tltl.so ]; then cp alt/tltl.so $LIB; for wl in c2 c4; do timeout 300 python tools/gpu_tile_timeline.py $wl > $OUT/tile_timeline_$wl.txt 2>&1; done; fi
-if [ -f alt/rsph.so ]; then cp alt/rsph.so $LIB; for wl in c2 c4; do timeout 300 python tools/gpu_rs_phases.py $wl > $OUT/rs_phases_$wl.txt 2>&1; done; fi
+for pair in "tltl gpu_tile_timeline tile_timeline" "rsph gpu_rs_phases rs_phases"; do
+  set -- $pair
+  if python tools/build_alt.py --check $1 > /dev/null; then
+    cp alt/$1.so $LIB
+    for wl in c2 c4; do
+      timeout 300 python tools/$2.py $wl > $OUT/$3_$wl.txt 2> $OUT/$3_$wl.err || { echo "$2 $wl FAILED (see $OUT/$3_$wl.err)"; rm -f $OUT/$3_$wl.txt; }
+    done
+    cp /tmp/final_base.so $LIB
+  else
+    echo "alt/$1.so is stale or missing: run  python tools/build_alt.py $1 ...  first; no timeline written"
+  fi
+done
 cp /tmp/final_base.so $LIB
 echo done

@@ -33,7 +33,6 @@
 //   framesBound(ctx), framesEnqueued(ctx), graphLaunches(ctx)
 #include <node_api.h>
 
-#include <atomic>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -65,8 +64,7 @@ napi_value throw_ht(napi_env env, ht_ctx *ctx, ht_status st, const char *where) 
 // takes `mu` for the duration of its C-ABI calls, so overlapping calls run one after the other, in lock-acquisition order.
 struct Slot {
     ht_ctx *ctx = nullptr;
-    std::atomic<int> refs{1};  // the context's JS handle + every device buffer allocated on it (their finalizers need the lock below)
-    std::recursive_mutex mu;  // recursive: a GC finalizer (device buffers) may run on the JS thread inside an entry point that holds it
+    std::recursive_mutex mu;
 };
 
 bool get_slot(napi_env env, napi_value v, Slot **out) {
@@ -141,31 +139,12 @@ void env_cleanup(void *) {
     }
 }
 
-// Finalizers never call back into N-API: Node 12 runs pending finalizers while it tears the environment down, and napi calls made from
-// them at that point crash inside libnode (seen as a SIGSEGV at exit in GlobalHandles::InvokeSecondPassPhantomCallbacks).
-void release_slot(Slot *slot) {
-    if (slot->refs.fetch_sub(1) != 1) return;
-    {
-        std::lock_guard<std::mutex> lk(g_slots_mu);
-        for (size_t i = 0; i < g_slots.size(); i++)
-            if (g_slots[i] == slot) {
-                g_slots.erase(g_slots.begin() + (long)i);
-                break;
-            }
-    }
-    delete slot;
-}
-
-void finalize_ctx(napi_env, void *data, void *) {
-    Slot *slot = static_cast<Slot *>(data);
-    {
-        std::lock_guard<std::recursive_mutex> lk(slot->mu);
-        if (slot->ctx) ht_destroy(slot->ctx);  // also frees the device buffers allocated on it
-        slot->ctx = nullptr;
-    }
-    release_slot(slot);
-}
-
+// NO finalizers on the handles this addon hands to JavaScript.  Node 12 runs finalizers that are still pending while it tears the
+// environment down, through N-API's own phantom-callback wrapper, and that wrapper crashes inside libnode (SIGSEGV at exit in
+// GlobalHandles::InvokeSecondPassPhantomCallbacks -> libnode, seen in one of two runs of tests/js/bench_host.js whatever the callback
+// did).  Native resources are therefore released explicitly — destroy(ctx), deviceFree(ctx, buf), hostFree(arr) — and, for whatever is
+// still alive at exit, by the environment's cleanup hook (env_cleanup), which is an ordinary callback, not a finalizer.  A handle that
+// is dropped without destroy() keeps its GPU memory until the process exits.
 napi_value CreateContext(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
@@ -210,7 +189,7 @@ napi_value CreateContext(napi_env env, napi_callback_info info) {
         g_slots.push_back(slot);
     }
     napi_value ext;
-    NAPI_OK(napi_create_external(env, slot, finalize_ctx, nullptr, &ext));
+    NAPI_OK(napi_create_external(env, slot, nullptr, nullptr, &ext));  // no finalizer, see release_slot
     return ext;
 }
 
@@ -626,8 +605,6 @@ napi_value AllgatherBest(napi_env env, napi_callback_info info) {
 
 // ---- pipelined path ------------------------------------------------------------------------------------------------------------
 
-void finalize_pinned(napi_env, void *data, void *) { ht_host_free(data); }
-
 napi_value HostAlloc(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
@@ -641,7 +618,7 @@ napi_value HostAlloc(napi_env env, napi_callback_info info) {
     ht_status st = ht_host_alloc((size_t)bytes, &p);
     if (st != HT_OK) return throw_ht(env, nullptr, st, "ht_host_alloc");
     napi_value ab, ta;
-    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, finalize_pinned, nullptr, &ab) != napi_ok) {
+    if (napi_create_external_arraybuffer(env, p, (size_t)bytes, nullptr, nullptr, &ab) != napi_ok) {  // no finalizer: hostFree(arr)
         ht_host_free(p);
         napi_throw_error(env, nullptr, "hostAlloc: napi_create_external_arraybuffer failed");
         return nullptr;
@@ -653,21 +630,10 @@ napi_value HostAlloc(napi_env env, napi_callback_info info) {
 // a device buffer: freed explicitly (deviceFree) or, at the latest, when the JS handle is collected — through the context it was
 // allocated on, which the handle keeps alive
 struct DevBuf {
-    Slot *slot = nullptr;  // holds one reference on the slot: the lock outlives the context's JS handle
+    Slot *slot = nullptr;  // Slots are never freed (a few bytes per context): a JS handle may outlive destroy()
     void *ptr = nullptr;
     size_t bytes = 0;
 };
-void finalize_devbuf(napi_env, void *data, void *) {
-    DevBuf *d = static_cast<DevBuf *>(data);
-    if (d->slot) {
-        {
-            std::lock_guard<std::recursive_mutex> lk(d->slot->mu);
-            if (d->ptr && d->slot->ctx) (void)ht_device_free(d->slot->ctx, d->ptr);  // a destroyed context has freed it already
-        }
-        release_slot(d->slot);
-    }
-    delete d;
-}
 bool get_devbuf(napi_env env, napi_value v, DevBuf **out) {
     void *p = nullptr;
     if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<DevBuf *>(p)->ptr || !static_cast<DevBuf *>(p)->slot->ctx) {
@@ -676,6 +642,21 @@ bool get_devbuf(napi_env env, napi_value v, DevBuf **out) {
     }
     *out = static_cast<DevBuf *>(p);
     return true;
+}
+
+// hostFree(Uint8Array from hostAlloc): releases the pinned memory; the array must not be used afterwards
+napi_value HostFree(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    uint8_t *p = nullptr;
+    size_t len = 0;
+    if (argc < 1 || !get_bytes(env, argv[0], &p, &len) || !p) {
+        napi_throw_type_error(env, nullptr, "hostFree(Uint8Array returned by hostAlloc)");
+        return nullptr;
+    }
+    ht_host_free(p);
+    return nullptr;
 }
 
 napi_value DeviceAlloc(napi_env env, napi_callback_info info) {
@@ -696,10 +677,9 @@ napi_value DeviceAlloc(napi_env env, napi_callback_info info) {
         return throw_ht(env, L.ctx, st, "ht_device_alloc");
     }
     get_slot(env, argv[0], &d->slot);
-    d->slot->refs.fetch_add(1);
     d->bytes = (size_t)bytes;
     napi_value ext;
-    NAPI_OK(napi_create_external(env, d, finalize_devbuf, nullptr, &ext));
+    NAPI_OK(napi_create_external(env, d, nullptr, nullptr, &ext));  // no finalizer: freed by deviceFree or with its context
     return ext;
 }
 
@@ -1042,7 +1022,7 @@ napi_value Init(napi_env env, napi_value exports) {
                {"whitebalance", Whitebalance},   {"camshiftReserve", CamshiftReserve},
                {"camshiftInit", CamshiftInit},   {"camshiftTrack", CamshiftTrack}, {"info", Info},
                {"deviceCount", DeviceCount},     {"allgatherBest", AllgatherBest},
-               {"hostAlloc", HostAlloc},         {"deviceAlloc", DeviceAlloc}, {"deviceFree", DeviceFree}, {"deviceUpload", DeviceUpload},
+               {"hostAlloc", HostAlloc},         {"hostFree", HostFree},       {"deviceAlloc", DeviceAlloc}, {"deviceFree", DeviceFree}, {"deviceUpload", DeviceUpload},
                {"upload", Upload},               {"bindDevice", BindDevice},   {"uploadAsync", UploadAsync}, {"swapFrames", SwapFrames},
                {"detectEnqueue", DetectEnqueue}, {"detectCollect", DetectCollect}, {"collectBest", CollectBest},
                {"detectWhitebalance", DetectWhitebalance}, {"whitebalanceBound", WhitebalanceBound},

@@ -112,6 +112,7 @@ function bindFrame(c, img, cascade, interval) {
   c.boundImg = img;
 }
 headtrackr.hostAlloc = function (bytes) { return addon().hostAlloc(bytes); }; /* Uint8Array over pinned host memory */
+headtrackr.hostFree = function (arr) { addon().hostFree(arr); }; /* explicit: the addon's handles carry no GC finalizers (see ht_napi.cc) */
 
 /* ---- ccv ------------------------------------------------------------------------------------------------------------ */
 

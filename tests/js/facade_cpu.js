@@ -63,7 +63,7 @@ try {
     check(typeof addon[k] === 'function', 'addon.' + k);
   });
   /* the pipelined path: every C-ABI export the throughput numbers are made of has a JS name (INTEGRATION.md lists the pairs) */
-  ['hostAlloc', 'deviceAlloc', 'deviceFree', 'deviceUpload', 'upload', 'bindDevice', 'uploadAsync', 'swapFrames', 'detectEnqueue', 'detectCollect', 'collectBest',
+  ['hostAlloc', 'hostFree', 'deviceAlloc', 'deviceFree', 'deviceUpload', 'upload', 'bindDevice', 'uploadAsync', 'swapFrames', 'detectEnqueue', 'detectCollect', 'collectBest',
     'detectWhitebalance', 'whitebalanceBound', 'camshiftReserve', 'camshiftInitBound', 'camshiftTrackBound', 'camshiftTrackCollect', 'camshiftTrackSequence',
     'camshiftSequenceCollect', 'framesBound', 'framesEnqueued', 'graphLaunches', 'setGeometry', 'info', 'destroy'].forEach(function (k) {
     check(typeof addon[k] === 'function', 'addon.' + k);

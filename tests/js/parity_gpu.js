@@ -279,6 +279,7 @@ job.facetrackr.forEach(function (cs) {
       check(r1.best[5] === 0 && r1.hits === 0, 'uploadAsync/swapFrames: frame 1 has no face');
       check(A.framesBound(hnd) === 1 && A.framesEnqueued(hnd) === 0, 'framesBound / framesEnqueued');
       A.destroy(hnd);
+      headtrackr.hostFree(pin);
     }
   }
   out.cs_parity = (out.cs_exact || 0) + '/' + (out.cs_total || 0);

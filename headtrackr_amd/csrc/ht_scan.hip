@@ -357,7 +357,11 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                     xx[1] = xx[0] + 1u;
                     valid[0] = in0 && xx[0] < (uint32_t)tw;
                     valid[1] = in0 && xx[1] < (uint32_t)tw;
-                    ht_gen_stage_0_pair(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), Fv[0], Fv[1]);
+#ifndef HT_TILE_PAIRPK
+#define HT_TILE_PAIRPK 1  // both windows of the pair in the two 16-bit halves of one register (v_perm_b32 gather, v_pk_min/max_u16); 0: one 32-bit chain per window
+#endif
+                    if (HT_TILE_PAIRPK) ht_gen_stage_0_pair(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), Fv[0], Fv[1]);
+                    else ht_gen_stage_0_pair_u32(lds + (valid[0] ? 2u * (yy[0] * PITCH0 + xx[0]) : 0u), Fv[0], Fv[1]);
                 } else {
 #pragma unroll
                     for (int u = 0; u < 2; u++) {

@@ -939,7 +939,9 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
     if (!c->enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_collect: nothing enqueued");
     HT_HIP(c, hipSetDevice(c->device));
     // counters + the first HT_PINNED_HITS hits in one go (pinned host memory), one synchronisation per batch
-    const uint32_t spec = std::min<uint32_t>(HT_PINNED_HITS, c->hit_capacity);
+    // (speculative: as many hits as a batch of this size usually has — 64 per frame, at least 256 —, not the whole staging buffer:
+    // a live feed's single frame would otherwise wait for a 196 KB copy it almost never needs; the rare excess is fetched below)
+    const uint32_t spec = std::min<uint32_t>(std::min<uint32_t>(HT_PINNED_HITS, c->hit_capacity), std::max<uint32_t>(256u, 64u * (uint32_t)std::max(c->enq_nframes, 1)));
     HT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_counters, sizeof(HtCounters), hipMemcpyDeviceToHost, c->stream));
     HT_HIP(c, hipMemcpyAsync(c->h_pinned + sizeof(HtCounters), c->d_hits, (size_t)spec * sizeof(ht_hit), hipMemcpyDeviceToHost, c->stream));
     // the whitebalance sums of THIS batch travel with its counters: a re-enqueue below (or any later enqueue) zeroes and refills the

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/gpu_rs_phases.py [c2|c4] — where a k_resample workgroup spends its life, from a -DHT_RS_PHASES build (bash tools/build_alt.sh
+"""tools/gpu_rs_phases.py [c2|c4] — where a k_resample workgroup spends its life, from a -DHT_RS_PHASES build (python tools/build_alt.py
 rsph HT_RS_PHASES=1; copy alt/rsph.so over the library).  Phases: 1 record + taps + first loads issued + barrier (once per workgroup);
 per frame of the group: 2 loop top, 3 source tile regs -> LDS (waits for the prefetched loads), 4 barrier, 5 next frame's loads issued +
 pixels, 6 stores + barrier."""

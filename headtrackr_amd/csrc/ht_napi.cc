@@ -35,10 +35,13 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
 #include <vector>
+
+#include <unistd.h>
 
 #include "headtrackr_hip.h"
 
@@ -659,6 +662,21 @@ napi_value HostFree(napi_env env, napi_callback_info info) {
     return nullptr;
 }
 
+// exitNow(code): destroys every live context (stream synchronised, device memory freed) and leaves with _exit — no atexit handlers,
+// no static destructors, no environment teardown.  For hosts that are done: a Node 12 process that used HIP from libuv pool threads
+// (detectAsync) has been seen to crash with SIGSEGV inside the runtime's own exit path after a complete, correct run.
+napi_value ExitNow(napi_env env, napi_callback_info info) {
+    size_t argc = 1;
+    napi_value argv[1];
+    int32_t code = 0;
+    if (napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr) == napi_ok && argc > 0) get_i32(env, argv[0], &code);
+    env_cleanup(nullptr);
+    fflush(stdout);
+    fflush(stderr);
+    _exit(code);
+    return nullptr;
+}
+
 napi_value DeviceAlloc(napi_env env, napi_callback_info info) {
     size_t argc = 2;
     napi_value argv[2];
@@ -1022,6 +1040,7 @@ napi_value Init(napi_env env, napi_value exports) {
                {"whitebalance", Whitebalance},   {"camshiftReserve", CamshiftReserve},
                {"camshiftInit", CamshiftInit},   {"camshiftTrack", CamshiftTrack}, {"info", Info},
                {"deviceCount", DeviceCount},     {"allgatherBest", AllgatherBest},
+               {"exitNow", ExitNow},
                {"hostAlloc", HostAlloc},         {"hostFree", HostFree},       {"deviceAlloc", DeviceAlloc}, {"deviceFree", DeviceFree}, {"deviceUpload", DeviceUpload},
                {"upload", Upload},               {"bindDevice", BindDevice},   {"uploadAsync", UploadAsync}, {"swapFrames", SwapFrames},
                {"detectEnqueue", DetectEnqueue}, {"detectCollect", DetectCollect}, {"collectBest", CollectBest},

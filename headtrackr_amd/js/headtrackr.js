@@ -112,6 +112,8 @@ function bindFrame(c, img, cascade, interval) {
   c.boundImg = img;
 }
 headtrackr.hostAlloc = function (bytes) { return addon().hostAlloc(bytes); }; /* Uint8Array over pinned host memory */
+/* leave the process NOW: live contexts are destroyed, stdout / stderr flushed, then _exit(code) — no runtime teardown (see ht_napi.cc) */
+headtrackr.exitNow = function (code) { addon().exitNow(code | 0); };
 headtrackr.hostFree = function (arr) { addon().hostFree(arr); }; /* explicit: the addon's handles carry no GC finalizers (see ht_napi.cc) */
 
 /* ---- ccv ------------------------------------------------------------------------------------------------------------ */

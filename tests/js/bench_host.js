@@ -100,5 +100,5 @@ const out = { node: process.version, cpus: require('os').cpus().length, cpu_mode
     out.tracker.same_result_as_reference = JSON.stringify(out.tracker.after_60_calls) === JSON.stringify(out.tracker_reference_js.after_60_calls);
     out.tracker.vs_reference_p50 = +(out.tracker_reference_js.p50_ms / out.tracker.p50_ms).toFixed(1);
   }
-  console.log(JSON.stringify(out));
+  process.stdout.write(JSON.stringify(out) + '\n', function () { headtrackr.exitNow(0); }); /* see ht_napi.cc exitNow: no runtime teardown */
 })().catch(function (e) { console.log(JSON.stringify({ error: String(e && e.stack || e) })); process.exit(1); });

@@ -113,7 +113,7 @@ struct HtTailTapRef {
 };
 
 // One drawImage call (host job list) and, with the tile fields filled in, one k_resample workgroup (device tile table).
-constexpr int HT_RS_SRC_ROWS = 76;   // k_resample LDS window: source rows per tile
+constexpr int HT_RS_SRC_ROWS = 75;   // k_resample LDS window: source rows per tile (3 staging passes of 25 rows; 16 * 4 * 1.1225 + 3 = 74.8 still fits)
 constexpr int HT_RS_MAX_PASSES = 4;  // k_resample: 16-row passes per tile at most
 struct HtResampleJob {
     uint32_t src_off, dst_off;

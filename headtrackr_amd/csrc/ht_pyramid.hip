@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "ht_internal.h"
 
@@ -132,6 +133,12 @@ constexpr int RS_SP = 160;                  // LDS source tile: bytes per row (6
 // height decides how much of it is amortised: with 16 rows (1 row per thread) the 260k waves of one C2 generation run
 // in ~32 occupancy rounds of ~4 us each.
 
+typedef unsigned int rs_u32x4 __attribute__((ext_vector_type(4)));
+typedef float rs_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 rs_buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+    const rs_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 typedef HtTap RsTap;  // {t, u: weights of b and a; a, b: source coordinates, absolute incl. the source rect origin}
 
 __device__ __forceinline__ RsTap rs_tap(int i, double r, int s, int origin) {
@@ -177,6 +184,16 @@ __device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap (&cx)
 // otherwise fuses p[0] and p[1] into ONE ds_read_u16 at an arbitrary byte address, and gfx950's LDS serves a misaligned
 // access lane by lane — 64 instead of 2 cycles per wave, measured with tools/micro/lds_unaligned_bench.hip; the first build of
 // the binary32 path ran 2.3x slower than the binary64 one because of it)
+// the right tap of a pair as a relaxed workgroup-scope atomic load: still a plain ds_read_u8 (with the immediate offset folded), but one the
+// optimiser does not fuse with its left neighbour into a ds_read_u16 at an arbitrary byte address
+// workgroup barrier that orders LDS accesses only: global loads / stores stay in flight across it
+#define RS_LDS_BARRIER()                                                     \
+    do {                                                                     \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");      \
+        __builtin_amdgcn_s_barrier();                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      \
+    } while (0)
+#define RS_LD1(ptr_) __hip_atomic_load((ptr_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
 __device__ __forceinline__ uint32_t rs_pixel_f64(const uint8_t *p, const uint8_t *p1, double cu, double ct, double ru, double rt) {
     const double top = __dadd_rn(__dmul_rn((double)p[0], cu), __dmul_rn((double)p1[0], ct));
     const double bot = __dadd_rn(__dmul_rn((double)p[RS_SP], cu), __dmul_rn((double)p1[RS_SP], ct));
@@ -200,72 +217,20 @@ __device__ __forceinline__ uint32_t rs_pixel_f64(const uint8_t *p, const uint8_t
 // ties (a quarter of all pixels) would all take the fallback: it is computed in integers instead, RNE included.
 constexpr float RS_EPS = 1.0f / 8192.0f;
 
-// The binary64 taps are only needed by the rare fallback (and the HT_DEBUG_RS_NOFAST build): they are fetched from the tap
-// tables in LDS there (coltap[k] = column tap of pixel k, rowtap = the row's tap) instead of living in 20 VGPRs.
-__device__ __forceinline__ uint32_t rs_pixels4_lds(const uint8_t *row, const int (&ia)[4], const int (&ib)[4], const RsTap *const (&coltap)[4],
-                                                   const float (&ctf)[4], const RsTap *rowtap, float rtf, int npx, uint32_t mode) {
-    uint32_t o = 0;
-#define cu(k) (coltap[k]->u)
-#define ct(k) (coltap[k]->t)
-#define ru (rowtap->u)
-#define rt (rowtap->t)
-    if (mode & 2u) {  // HT_DEBUG_RS_NOFAST: the declared binary64 sequence for every pixel (A/B and cross-check)
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-            if (k < npx) o |= rs_pixel_f64(row + ia[k], row + ib[k], cu(k), ct(k), ru, rt) << (8 * k);
-        return o;
-    }
-    if (mode & 1u) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (k < npx) {
-                const uint8_t *p = row + ia[k], *p1 = row + ib[k];
-                const uint32_t sum = (uint32_t)p[0] + p1[0] + p[RS_SP] + p1[RS_SP];
-                const uint32_t q = sum >> 2, r = sum & 3u;
-                o |= (q + ((r + (q & 1u)) > 2u ? 1u : 0u)) << (8 * k);  // RNE(sum / 4): up on .75, on .5 only to the even neighbour
-            }
-        }
-        return o;
-    }
-    // v_cvt_pk_u8_f32 converts and inserts a byte in one instruction (its input is already integral: no rounding-mode question), and
-    // the distances to the nearest rounding boundary are tested once per 4 pixels (max of the four |v - r|) instead of with a compare +
-    // select + or per pixel.
-    float d[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        if (k < npx) {
-            const uint8_t *p = row + ia[k], *p1 = row + ib[k];
-            const float p00 = (float)p[0], p01 = (float)p1[0], p10 = (float)p[RS_SP], p11 = (float)p1[RS_SP];
-            const float top = __builtin_fmaf(ctf[k], p01 - p00, p00);
-            const float bot = __builtin_fmaf(ctf[k], p11 - p10, p10);
-            const float v = __builtin_fmaf(rtf, bot - top, top);
-            const float r = __builtin_rintf(v);
-            d[k] = v - r;
-            o = __builtin_amdgcn_cvt_pk_u8_f32(r, k, o);
-        }
-    }
-    const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[0]), __builtin_fabsf(d[1])), __builtin_fmaxf(__builtin_fabsf(d[2]), __builtin_fabsf(d[3])));
-    if (dmax >= 0.5f - RS_EPS) {  // rare: the declared binary64 sequence for the pixels next to a rounding boundary
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            if (k < npx && __builtin_fabsf(d[k]) >= 0.5f - RS_EPS) {
-                o &= ~(0xffu << (8 * k));
-                o |= rs_pixel_f64(row + ia[k], row + ib[k], cu(k), ct(k), ru, rt) << (8 * k);
-            }
-        }
-    }
-    return o;
-#undef cu
-#undef ct
-#undef ru
-#undef rt
-}
-
 #ifndef HT_RS_WPS
-#define HT_RS_WPS 6  // waves per SIMD the register allocator leaves room for: 78 VGPRs without spills (measured: 5 -> 6 waves -5 %; 7 / 8 spill and lose)
+#define HT_RS_WPS 6  // waves per SIMD the register allocator must leave room for (6: <= 80 VGPRs, 5: <= 96)
+#endif
+// Measured on one box, device ms per step of the pyramid generations 1-5 at 128 x 720p / bench frames/s (profiles/r03_resample_ab.txt):
+// round-2 loop 0.503 / 110.9 k; flat loop 6 waves 0.472 / 116.0 k; + packed 0.472 / 116.3 k; flat loop with the next row's taps in flight
+// (needs 5 waves: 84 VGPRs) 0.490 / 112.9 k; the same + packed 0.491 / 112.3 k.
+#ifndef HT_RS_ROWPF
+#define HT_RS_ROWPF 0  // 1 = the 16 taps of the next row are in flight while a row is evaluated (32 tap registers: needs HT_RS_WPS 5), 0 = one row at a time
+#endif
+#ifndef HT_RS_PACKED
+#define HT_RS_PACKED 1  // 1 = top / bot of a pixel as one packed pair (v_pk_add_f32 + v_pk_fma_f32: 4.5 cycles for two, tools/micro/valu_rate_bench.hip)
 #endif
 #ifndef HT_RS_EXPERIMENT
-#define HT_RS_EXPERIMENT 0  // timing experiments only (results are wrong): 1 = no pixel arithmetic, 2 = no source loads
+#define HT_RS_EXPERIMENT 0  // timing experiments only (results are wrong): 1 = no pixel arithmetic, 2 = no source loads after the first frame, 3 = no stores
 #endif
 #if defined(HT_RS_PHASES)  // tools/gpu_rs_phases.py: shader-clock stamps of every phase of every frame iteration, plain stores into per-workgroup slots
 __device__ unsigned long long g_rs_tl[16384][8][8];  // [slot][frame iteration & 7][stamp]
@@ -347,116 +312,254 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
             sw16 = (rs_tap(X0 + ncols - 1, J.rx, J.sw, J.sx).b - xa) / 16 + 1;  // 16-byte chunks per source row
             sh = rs_tap(Y0 + nrows - 1, J.ry, J.sh, J.sy).b - ya + 1;           // source rows
         }
+        // workgroup-uniform whichever branch produced them (the device path computes them with vector binary64 instructions): scalar registers
+        xa = __builtin_amdgcn_readfirstlane(xa), ya = __builtin_amdgcn_readfirstlane(ya);
+        sw16 = __builtin_amdgcn_readfirstlane(sw16), sh = __builtin_amdgcn_readfirstlane(sh);
         in_lds = (sw16 * 16 <= RS_SP) && (sh <= SR);
     }
     RS_SUB(1);
     if (in_lds) {
-        // source rows as 16-byte chunks.  10 threads share a row (= the 160-byte LDS pitch), 25 rows per pass.  Plane
-        // strides are only 4-byte multiples, so the chunks are dword- not 16-byte-aligned in HBM and may run past the
-        // row's end into the next row / plane of the same arena (never used: see rs_pixels4_lds).  Loads are
-        // unconditional with clamped coordinates (duplicates fall into cache lines the wave fetches anyway); only the
-        // LDS writes are predicated.
+        // source rows as 16-byte chunks.  10 threads share a row (= the 160-byte LDS pitch), 25 rows per pass, 3 passes (SR = 75 rows).
+        // Plane strides are only 4-byte multiples, so the chunks are dword- not 16-byte-aligned in HBM and may run past the row's
+        // end into the next row / plane of the same arena (never used: a clamped tap has weight 0, see rs_pixel_f64).  Loads are
+        // unconditional with clamped coordinates (duplicates fall into cache lines the wave fetches anyway); only the LDS writes
+        // are predicated.
+        //
+        // Frame loop (round 3).  The loop of rounds 1-2 compiled to one basic block PER PIXEL (`if (k < npx)`, the mode tests and
+        // the row tests were re-evaluated per pixel / per row): the four ds_read_u8 of a pixel were issued and waited for inside
+        // that pixel's block, so a frame iteration was a chain of 16 dependent LDS round trips per thread, and the row taps were
+        // re-read from LDS (with a v_cvt_f32_f64 and a v_mul_lo_u32) for every row of every frame — ~27 VALU instructions per pixel,
+        // which is why the kernel "did not respond to instruction counts".  Now
+        //   * everything that depends only on the tile geometry is computed ONCE per workgroup (row offsets, row weights as
+        //     binary32, byte mask, store predicates);
+        //   * the loop is specialised on the number of passes (NP) and on the box mode, and a row is straight-line code: every tap
+        //     is loaded from CLAMPED coordinates whether or not its pixel is drawn (the byte mask zeroes what lies outside dw x dh),
+        //     and the 16 taps of row q + 1 are in flight while row q is evaluated (~16 VALU instructions per pixel);
+        //   * global memory is addressed through a buffer descriptor of the frame (scalar registers) + 32-bit per-thread offsets +
+        //     a scalar offset: no 64-bit per-thread address arithmetic, nothing for loop strength reduction to turn into per-thread
+        //     induction variables;
+        //   * the staging registers of the prefetched source tile are live only inside an iteration (load issue -> LDS write), not
+        //     across the tap tables and the variant switch, where the register allocator used to spill them.
         constexpr int KR = (SR + 24) / 25;
+        static_assert(KR == 3, "the staging registers below are written out for three passes");
         const int r0 = (tid * 205) >> 11, c16 = tid - r0 * 10;  // tid / 10, tid % 10 for tid < 256
         const bool lane_on = (r0 < 25) && (c16 < sw16);
-        // addresses = uniform frame base (scalar registers) + 32-bit per-thread offsets
+        // addresses = the frame's buffer descriptor (scalar registers) + 32-bit per-thread offsets
         const uint32_t soff = J.src_off + (uint32_t)(ya * J.src_stride + xa + 16 * min(c16, sw16 - 1));
-        static_assert(KR == 4, "the staging registers below are written out for four passes");
         const uint32_t soff0 = soff + (uint32_t)(min(r0, sh - 1) * J.src_stride), soff1 = soff + (uint32_t)(min(r0 + 25, sh - 1) * J.src_stride);
-        const uint32_t soff2 = soff + (uint32_t)(min(r0 + 50, sh - 1) * J.src_stride), soff3 = soff + (uint32_t)(min(r0 + 75, sh - 1) * J.src_stride);
-        uint4 v0, v1, v2, v3;  // named scalars: an array assigned under `if (f + 1 < f1)` is demoted to scratch
-#ifndef HT_RS_PF2
-#define HT_RS_PF2 0  // 1: the source tiles of the next TWO frames are in flight (a second set of 16 staging registers)
-#endif
-#if HT_RS_PF2
-        uint4 w0, w1, w2, w3;
-#endif
-#define RS_LOAD_TILE_INTO(base, r0_, r1_, r2_, r3_)                     \
-    do {                                                                \
-        r0_ = *reinterpret_cast<const uint4 *>((base) + soff0);         \
-        r1_ = *reinterpret_cast<const uint4 *>((base) + soff1);         \
-        r2_ = *reinterpret_cast<const uint4 *>((base) + soff2);         \
-        r3_ = *reinterpret_cast<const uint4 *>((base) + soff3);         \
+        const uint32_t soff2 = soff + (uint32_t)(min(r0 + 50, sh - 1) * J.src_stride);
+        uint8_t *const sdst = &s_src[r0 * RS_SP + 16 * c16];
+        const bool w0on = lane_on && r0 < sh, w1on = lane_on && r0 + 25 < sh, w2on = lane_on && r0 + 50 < sh;
+        uint64_t fbase = reinterpret_cast<uint64_t>(frame);
+        // raw buffer (stride 0) over a frame's arena; 0x00020000 = the gfx9 data-format word; offsets stay inside the arena
+#define RS_FRAME_RSRC(base_) __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base_), 0, (int)0xffffffffu, 0x00020000)
+#define RS_TILE_TO_LDS()                                                          \
+    do {                                                                          \
+        if (w0on) *reinterpret_cast<uint4 *>(sdst) = v0;                          \
+        if (w1on) *reinterpret_cast<uint4 *>(sdst + 25 * RS_SP) = v1;             \
+        if (w2on) *reinterpret_cast<uint4 *>(sdst + 50 * RS_SP) = v2;             \
     } while (0)
-#define RS_LOAD_TILE(base) RS_LOAD_TILE_INTO(base, v0, v1, v2, v3)
         RS_SUB(2);
-        RS_LOAD_TILE(frame);
-#if HT_RS_PF2
-        if (f0 + 1 < f1) RS_LOAD_TILE_INTO(frame + arena_stride, w0, w1, w2, w3);
-#endif
-        RS_SUB(3);
-        if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
-        if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
-        RS_SUB(4);
+        {
+            // the first frame's tile: loads issued, tap tables computed while they are in flight, then tile + tables behind ONE barrier
+            const __amdgpu_buffer_rsrc_t fr = RS_FRAME_RSRC(fbase);
+            const uint4 v0 = rs_buf_load16(fr, soff0, 0u), v1 = rs_buf_load16(fr, soff1, 0u), v2 = rs_buf_load16(fr, soff2, 0u);
+            RS_SUB(3);
+            if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
+            if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
+            RS_SUB(4);
+            RS_TILE_TO_LDS();
+        }
         __syncthreads();
         if (HT_RS_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         RS_STAMP(1);
-        int ia[4], ib[4];
-        const RsTap *coltap[4];
+        const int cbase = x0 - X0;  // first column of this thread inside the tile
+        int ia[4];
         float ctf[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            coltap[k] = &s_col[min(x0 - X0 + k, ncols - 1)];
-            ia[k] = coltap[k]->a - xa, ctf[k] = (float)coltap[k]->t;
-            ib[k] = ia[k] + 1;
-            asm volatile("" : "+v"(ib[k]));  // opaque to the optimiser: keeps the left / right taps separate ds_read_u8 (see rs_pixel_f64)
+            const RsTap *ct = &s_col[min(cbase + k, ncols - 1)];
+            ia[k] = ct->a - xa, ctf[k] = (float)ct->t;
         }
+        // the right taps are read at p + 1 — with a "1" the optimiser cannot see: hipcc otherwise fuses p[0] and p[1] into ONE
+        // ds_read_u16 at an arbitrary byte address (see rs_pixel_f64)
+        uint32_t one = 1u;
+        asm volatile("" : "+s"(one));
         const uint32_t mode = J.pad;  // bit 0: 2x2 box mean (both ratios exactly 2), bit 1: binary64 everywhere (set by the host)
-        const int dh = J.dh, ch = J.ch, dst_stride = J.dst_stride;  // locals: not re-read from the record after each store
+        // binary64 everywhere (HT_DEBUG_RS_NOFAST) = every pixel takes the fallback: a threshold no distance can stay under
+        const float thr = (mode & 2u) ? -1.0f : 0.5f - RS_EPS;
+        const int dh = J.dh, ch = J.ch, dst_stride = J.dst_stride;
         const uint32_t doff = J.dst_off + (uint32_t)(yt * dst_stride + x0);
-        // one frame: staged registers -> LDS, barrier, refill the registers with a later frame's tile, pixels, stores
-        auto step = [&](uint4 &r0_, uint4 &r1_, uint4 &r2_, uint4 &r3_, uint32_t f, uint32_t ahead) {
-            RS_STAMP(2);
-            uint8_t *sdst = &s_src[r0 * RS_SP + 16 * c16];
-            if (lane_on && r0 < sh) *reinterpret_cast<uint4 *>(sdst) = r0_;
-            if (lane_on && r0 + 25 < sh) *reinterpret_cast<uint4 *>(sdst + 25 * RS_SP) = r1_;
-            if (lane_on && r0 + 50 < sh) *reinterpret_cast<uint4 *>(sdst + 50 * RS_SP) = r2_;
-            if (lane_on && r0 + 75 < sh) *reinterpret_cast<uint4 *>(sdst + 75 * RS_SP) = r3_;
-            RS_STAMP(3);
-            __syncthreads();
-            RS_STAMP(4);
-            if (f + ahead < f1) {  // a later frame's source tile: in flight during this frame's pixels
-                RS_LOAD_TILE_INTO(frame + (uint64_t)ahead * arena_stride, r0_, r1_, r2_, r3_);
-            }
-            if (HT_RS_PRIO >= 2) __builtin_amdgcn_s_setprio(0);  // the pixel arithmetic yields to wavefronts that are staging / issuing loads
-            uint32_t o[RPT];
+        const uint32_t pxmask = npx >= 4 ? 0xffffffffu : (npx <= 0 ? 0u : ((1u << (8 * npx)) - 1u));
+        const int ia8 = npx > 0 ? ia[0] : 0;  // box mode: 8 consecutive source bytes of the thread's 4 pixels (8-byte aligned: x0 % 4 == 0, xa % 16 == 0, sx == 0)
+        auto frames = [&](auto NPc, auto BOXc) {
+            constexpr int NP = decltype(NPc)::value;
+            constexpr bool BOX = decltype(BOXc)::value;
+            uint32_t roff[NP];
+            float rtf[NP];
+            bool st[NP], rv[NP];
 #pragma unroll
-            for (int q = 0; q < RPT; q++) {
+            for (int q = 0; q < NP; q++) {
                 const int y = yt + 16 * q;
-                o[q] = 0;
-                if (q < np && y < dh && npx > 0) {
-                    const RsTap *ry = &s_row[y - Y0];
-                    if (HT_RS_EXPERIMENT == 1) o[q] = *reinterpret_cast<const uint32_t *>(s_src + (ry->a - ya) * RS_SP + (ia[0] & ~3));
-                    else o[q] = rs_pixels4_lds(s_src + (ry->a - ya) * RS_SP, ia, ib, coltap, ctf, ry, (float)ry->t, npx, mode);
-                }
+                const RsTap *ry = &s_row[min(y - Y0, nrows - 1)];
+                roff[q] = (uint32_t)((ry->a - ya) * RS_SP);
+                rtf[q] = (float)ry->t;
+                rv[q] = y < dh;  // a drawn row (pxmask is 0 where the thread has no drawn column)
+                st[q] = y < ch && x0 < dst_stride;
             }
+            for (uint32_t f = f0; f < f1; f++) {
+                asm volatile("" : "+s"(fbase));  // opaque per iteration: the frame base stays ONE scalar value
+                const __amdgpu_buffer_rsrc_t fr = RS_FRAME_RSRC(fbase);
+                fbase += arena_stride;
+                // the tap addresses roff[q] + ia[k] are loop invariants, but 32 of them do not fit the register budget: keep them from being hoisted
+#pragma unroll
+                for (int q = 0; q < NP; q++) asm volatile("" : "+v"(roff[q]));
+                RS_STAMP(2);
+                uint4 v0, v1, v2;
+                if (f + 1 < f1 && HT_RS_EXPERIMENT != 2) {  // the next frame's source tile (scalar offset = one arena): in flight during this frame's pixels
+                    v0 = rs_buf_load16(fr, soff0, (uint32_t)arena_stride);
+                    v1 = rs_buf_load16(fr, soff1, (uint32_t)arena_stride);
+                    v2 = rs_buf_load16(fr, soff2, (uint32_t)arena_stride);
+                }
+                RS_STAMP(3);
+                uint32_t o[NP];
+                if (HT_RS_EXPERIMENT == 1) {  // timing experiment (wrong results): no pixel arithmetic, one LDS read per row
+#pragma unroll
+                    for (int q = 0; q < NP; q++) o[q] = *reinterpret_cast<const uint32_t *>(s_src + roff[q] + (ia8 & ~3));
+                } else if (BOX) {
+                    // exact 2:1 in both directions: (a + b + c + d) / 4 with round half to even.  The 4 pixels of a thread are 8 consecutive
+                    // bytes of two source rows: two ds_read_b64 per row instead of 16 byte reads; v_perm_b32 gathers a pixel's four bytes,
+                    // v_sad_u8 adds them, and RNE(sum / 4) is exact in binary32 (sum <= 1020).
+#pragma unroll
+                    for (int q = 0; q < NP; q++) {
+                        const uint8_t *row = s_src + roff[q] + ia8;
+                        const uint2 A = *reinterpret_cast<const uint2 *>(row), B = *reinterpret_cast<const uint2 *>(row + RS_SP);
+                        uint32_t oq = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t a = k < 2 ? A.x : A.y, b = k < 2 ? B.x : B.y;
+                            // v_perm_b32(src0 = b, src1 = a): selector bytes 0-3 pick from a, 4-7 from b
+                            const uint32_t g = __builtin_amdgcn_perm(b, a, (k & 1) ? 0x07060302u : 0x05040100u);
+                            const uint32_t sum = __builtin_amdgcn_sad_u8(g, 0u, 0u);
+                            oq = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf((float)sum * 0.25f), k, oq);
+                        }
+                        o[q] = rv[q] ? (oq & pxmask) : 0u;
+                    }
+                } else {
+                    // The declared value needs binary64 only where it decides something (see RS_EPS above): every pixel is evaluated in
+                    // binary32 first — top = p00 + tx * (p01 - p00), bot likewise, v = top + ty * (bot - top): three v_fma_f32 —, stored
+                    // with v_cvt_pk_u8_f32 (its input is already integral), and the distance to the nearest rounding boundary is tested once
+                    // per row (max of the four |v - r|).
+                    uint32_t T[2][16];
+#define RS_TAPS(q_, buf_)                                                                                   \
+    do {                                                                                                    \
+        const uint8_t *row_ = s_src + roff[q_];                                                             \
+        _Pragma("unroll") for (int k = 0; k < 4; k++) {                                                     \
+            const uint8_t *p_ = row_ + ia[k];                                                               \
+            T[buf_][4 * k] = p_[0], T[buf_][4 * k + 1] = RS_LD1(p_ + 1), T[buf_][4 * k + 2] = p_[RS_SP], T[buf_][4 * k + 3] = RS_LD1(p_ + RS_SP + 1); \
+        }                                                                                                   \
+    } while (0)
+                    if (HT_RS_ROWPF) {
+                        RS_TAPS(0, 0);
+                        __builtin_amdgcn_sched_barrier(0);  // row 0's taps first: its arithmetic only waits for them
+                    }
+#pragma unroll
+                    for (int q = 0; q < NP; q++) {
+                        if (HT_RS_ROWPF) {
+                            if (q + 1 < NP) RS_TAPS(q + 1, (q + 1) & 1);
+                        } else {
+                            RS_TAPS(q, q & 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);  // the loads above are not sunk into the arithmetic below
+                        float d[4];
+                        uint32_t oq = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float p00 = (float)T[q & 1][4 * k], p01 = (float)T[q & 1][4 * k + 1], p10 = (float)T[q & 1][4 * k + 2], p11 = (float)T[q & 1][4 * k + 3];
+#if HT_RS_PACKED  // top and bot of a pixel as one packed pair: v_pk_add_f32 + v_pk_fma_f32 instead of two v_sub_f32 + two v_fma_f32
+                            const rs_f2 lo2 = {p00, p10}, hi2 = {p01, p11}, ct2 = {ctf[k], ctf[k]};
+                            const rs_f2 tb = __builtin_elementwise_fma(ct2, hi2 - lo2, lo2);
+                            const float top = tb.x, bot = tb.y;
+#else
+                            const float top = __builtin_fmaf(ctf[k], p01 - p00, p00);
+                            const float bot = __builtin_fmaf(ctf[k], p11 - p10, p10);
+#endif
+                            const float v = __builtin_fmaf(rtf[q], bot - top, top);
+                            const float r = __builtin_rintf(v);
+                            d[k] = v - r;
+                            oq = __builtin_amdgcn_cvt_pk_u8_f32(r, k, oq);
+                        }
+                        const float dmq = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[0]), __builtin_fabsf(d[1])), __builtin_fmaxf(__builtin_fabsf(d[2]), __builtin_fabsf(d[3])));
+                        if (dmq >= thr) {  // rare (2.4e-4 of the pixels): the declared binary64 sequence for the pixels next to a rounding boundary
+                            // everything the fallback needs is derived HERE from values made opaque inside the branch: as loop invariants its
+                            // table addresses would be hoisted in front of the loop and held in registers the common path needs
+                            uint32_t roff_f = roff[q];
+                            int yrel = yt - Y0, cb = cbase;
+                            asm volatile("" : "+v"(roff_f), "+v"(yrel), "+v"(cb));  // (also: the fallback re-reads its taps instead of keeping all 16 bytes of every row alive)
+                            const RsTap *ry = &s_row[min(yrel + 16 * q, nrows - 1)];
+                            const uint8_t *rowf = s_src + roff_f;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (__builtin_fabsf(d[k]) >= thr) {
+                                    const RsTap *ct = &s_col[min(cb + k, ncols - 1)];
+                                    oq &= ~(0xffu << (8 * k));
+                                    oq |= rs_pixel_f64(rowf + ia[k], rowf + ia[k] + one, ct->u, ct->t, ry->u, ry->t) << (8 * k);
+                                }
+                            }
+                        }
+                        o[q] = rv[q] ? (oq & pxmask) : 0u;
+                    }
+#undef RS_TAPS
+                }
 #ifdef HT_RS_TIMELINE
 #pragma unroll
-            for (int q = 0; q < RPT; q++) asm volatile("" ::"v"(o[q]));
-            RS_STAMP(5);
+                for (int q = 0; q < NP; q++) asm volatile("" ::"v"(o[q]));
+                RS_STAMP(4);
 #endif
-            // pixels outside the drawn dw x dh rect stay transparent black (ccv.js:135-145 draws 2 px short on the variants)
-#pragma unroll
-            for (int q = 0; q < RPT; q++) {
-                const int y = yt + 16 * q;
-                if (q < np && y < ch && x0 < dst_stride) *reinterpret_cast<uint32_t *>(frame + (doff + (uint32_t)(16 * q * dst_stride))) = o[q];
-            }
-            if (HT_RS_PRIO >= 2) __builtin_amdgcn_s_setprio(3);
-            if (f + 1 < f1) __syncthreads();  // every wave is done reading this frame's tile
-            RS_STAMP(6);
+                // Barriers inside the loop order LDS accesses only (fence restricted to the local address space: s_waitcnt lgkmcnt(0) + s_barrier).
+                // __syncthreads() also waits for vmcnt(0), i.e. for this iteration's global STORES to be acknowledged and for the prefetched
+                // loads: measured (HT_RS_PHASES, 720p) a workgroup spent 8 300 of its 11 500 cycles per frame parked there.  The stores are
+                // issued after the next tile has been written to LDS, so whoever waits for loads next (vmcnt cannot tell loads from older
+                // stores) finds them a whole pixel phase old.
+                // pixels outside the drawn dw x dh rect stay transparent black (ccv.js:135-145 draws 2 px short on the variants)
+#define RS_STORE_ROWS()                                                                                                                             \
+    _Pragma("unroll") for (int q = 0; q < NP; q++) if (st[q] && (HT_RS_EXPERIMENT != 3 || o[q] == 0x12345678u))                                     \
+        __builtin_amdgcn_raw_buffer_store_b32(o[q], fr, doff, (uint32_t)(16 * q * dst_stride), 0)
+                if (f + 1 < f1) {
+                    RS_LDS_BARRIER();  // every wave is done reading this frame's tile
+                    RS_STAMP(5);
+                    if (HT_RS_EXPERIMENT != 2) RS_TILE_TO_LDS();
+                    RS_STORE_ROWS();
+                    RS_LDS_BARRIER();
+                } else {
+                    RS_STORE_ROWS();
+                    RS_STAMP(5);
+                }
+#undef RS_STORE_ROWS
+                RS_STAMP(6);
 #ifdef HT_RS_PHASES
-            rs_iter++;
+                rs_iter++;
 #endif
-            frame += arena_stride;
+            }
         };
-#if HT_RS_PF2
-        for (uint32_t f = f0; f < f1; f += 2) {
-            step(v0, v1, v2, v3, f, 2u);
-            if (f + 1 < f1) step(w0, w1, w2, w3, f + 1, 2u);
+        using std::integral_constant;
+        if (mode & 1u) {
+            switch (np) {
+                case 1: frames(integral_constant<int, 1>{}, integral_constant<bool, true>{}); break;
+                case 2: frames(integral_constant<int, 2>{}, integral_constant<bool, true>{}); break;
+                case 3: frames(integral_constant<int, 3>{}, integral_constant<bool, true>{}); break;
+                default: frames(integral_constant<int, RPT>{}, integral_constant<bool, true>{}); break;
+            }
+        } else {
+            switch (np) {
+                case 1: frames(integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+                case 2: frames(integral_constant<int, 2>{}, integral_constant<bool, false>{}); break;
+                case 3: frames(integral_constant<int, 3>{}, integral_constant<bool, false>{}); break;
+                default: frames(integral_constant<int, RPT>{}, integral_constant<bool, false>{}); break;
+            }
         }
-#else
-        for (uint32_t f = f0; f < f1; f++) step(v0, v1, v2, v3, f, 1u);
-#endif
+#undef RS_TILE_TO_LDS
+#undef RS_FRAME_RSRC
         return;
     }
     // nothing drawn in this tile (transparent black), or a source span larger than the LDS window (ratios > 2.3: the

@@ -68,7 +68,7 @@ def test_no_kernel_spills_registers():
     """Code-object metadata of the built library (llvm-readelf --notes, no GPU needed): no kernel spills VGPRs or SGPRs and none
     needs scratch memory — in particular k_cs_track_fused<true>, the kernel that is 80 % of C3's GPU time (it used to carry 52
     spilled VGPRs and 212 B of scratch per lane); and the occupancy-critical budgets hold (tile scan <= 80 VGPRs for 6 workgroups
-    per CU, the 1024-thread camshift kernels <= 128)."""
+    per CU, the resampler <= 80 likewise, the 1024-thread camshift kernels <= 128)."""
     import importlib.util
 
     from headtrackr_amd import build
@@ -81,5 +81,6 @@ def test_no_kernel_spills_registers():
     assert len(res) >= 20 and "k_cs_track_fused<true>" in res and "k_scan_tiles<true>" in res
     for name, r in res.items():
         assert r["vgpr_spill_count"] == 0 and r["sgpr_spill_count"] == 0 and r["private_segment_fixed_size"] == 0, (name, r)
-    assert res["k_scan_tiles<true>"]["vgpr_count"] <= 80 and res["k_resample<4>"]["vgpr_count"] <= 80
+    assert res["k_scan_tiles<true>"]["vgpr_count"] <= 80
+    assert res["k_resample<4>"]["vgpr_count"] <= 80  # 6 waves per SIMD
     assert res["k_cs_track_fused<true>"]["vgpr_count"] <= 128 and res["k_cs_track_fused<false>"]["vgpr_count"] <= 128

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """tools/gpu_rs_phases.py [c2|c4] — where a k_resample workgroup spends its life, from a -DHT_RS_PHASES build (python tools/build_alt.py
 rsph HT_RS_PHASES=1; copy alt/rsph.so over the library).  Phases: 1 record + taps + first loads issued + barrier (once per workgroup);
-per frame of the group: 2 loop top, 3 source tile regs -> LDS (waits for the prefetched loads), 4 barrier, 5 next frame's loads issued +
-pixels, 6 stores + barrier."""
+per frame of the group: 2 loop top, 3 next frame's loads issued, 4 pixels, 5 stores issued + barrier (every wave done with the tile),
+6 wait for the prefetched loads + registers -> LDS + barrier."""
 import ctypes as C
 import os
 import sys
@@ -29,7 +29,7 @@ for rep in range(3):
 lib.ht_debug_rs_phases(raw.ctypes.data, 1)
 cyc, cnt = raw[:8].astype(np.float64), raw[8:].astype(np.float64)
 tot = cyc.sum()
-names = {1: "setup + first loads + barrier", 2: "stamp 1 -> first loop top", 3: "regs -> LDS (load wait)", 4: "barrier", 5: "prefetch issue + pixels", 6: "stores + barrier"}
+names = {1: "setup + first loads + barrier", 2: "stamp 1 -> first loop top", 3: "prefetch issue", 4: "pixels", 5: "stores + barrier", 6: "load wait + regs -> LDS + barrier"}
 print(f"{wl}: {int(cnt[3])} frame iterations sampled, mean iteration {sum(cyc[3:7]) / max(cnt[3], 1):.0f} cycles")
 for p in range(1, 7):
     if cnt[p] > 0:

@@ -128,7 +128,12 @@ __global__ __launch_bounds__(256) void k_gray_inplace(uint8_t *__restrict__ fram
 //   3. every thread produces 4 pixels from LDS bytes: top/bot/v lerps, v_rndne_f64 (round half to even), one dword store.
 // Tiles whose source span does not fit (only the last 1-3 pixel levels, where the ratio can reach 6) read HBM directly.
 constexpr int RS_TW = 64;                   // destination tile width; its height is 16 * RPT (RPT rows per thread)
-constexpr int RS_SP = 160;                  // LDS source tile: bytes per row (64 * 2.04 + 2, dword aligned start)
+#ifndef HT_RS_PITCH
+#define HT_RS_PITCH 160
+#endif
+constexpr int RS_ROWB = 160;                // LDS source tile: payload bytes per row (64 * 2.04 + 2, dword aligned start; 10 threads x 16 bytes)
+constexpr int RS_SP = HT_RS_PITCH;          // ... and its row pitch (a multiple of 16: rows are written as 16-byte chunks)
+static_assert(RS_SP >= RS_ROWB && RS_SP % 16 == 0, "RS_SP");
 // A workgroup's latency chain (taps -> barrier -> HBM loads -> barrier -> LDS reads -> store) is fixed, so the tile
 // height decides how much of it is amortised: with 16 rows (1 row per thread) the 260k waves of one C2 generation run
 // in ~32 occupancy rounds of ~4 us each.
@@ -234,6 +239,13 @@ constexpr float RS_EPS = 1.0f / 8192.0f;
 #endif
 #if defined(HT_RS_PHASES)  // tools/gpu_rs_phases.py: shader-clock stamps of every phase of every frame iteration, plain stores into per-workgroup slots
 __device__ unsigned long long g_rs_tl[16384][8][8];  // [slot][frame iteration & 7][stamp]
+__device__ unsigned long long g_rs_tw[4096][4][6];   // per WAVE, third frame iteration of a workgroup: pixel start, pixel end, after barrier 1, after barrier 2, HW_ID
+#define RS_WSTAMP(i)                                                                                                                  \
+    do {                                                                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+        if (rs_iter == 2u && (threadIdx.x & 63u) == 0) g_rs_tw[rs_slot & 4095u][threadIdx.x >> 6][i] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                            \
+    } while (0)
 #define HT_RS_TIMELINE 1
 #define RS_SUB(i)                                                                       \
     do {                                                                                \
@@ -260,6 +272,9 @@ __device__ unsigned long long g_rs_timeline[1 << 16][8];
 #endif
 #ifndef RS_SUB
 #define RS_SUB(i)
+#endif
+#ifndef RS_WSTAMP
+#define RS_WSTAMP(i)
 #endif
 // One workgroup = one tile record x one group of K consecutive frames.  A tile is 64 columns x (16 * np) rows of one
 // drawImage call, np <= RPT passes chosen per tile by the host (ht_context.hip) so that (a) a level's rows are split
@@ -315,7 +330,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         // workgroup-uniform whichever branch produced them (the device path computes them with vector binary64 instructions): scalar registers
         xa = __builtin_amdgcn_readfirstlane(xa), ya = __builtin_amdgcn_readfirstlane(ya);
         sw16 = __builtin_amdgcn_readfirstlane(sw16), sh = __builtin_amdgcn_readfirstlane(sh);
-        in_lds = (sw16 * 16 <= RS_SP) && (sh <= SR);
+        in_lds = (sw16 * 16 <= RS_ROWB) && (sh <= SR);
     }
     RS_SUB(1);
     if (in_lds) {
@@ -422,6 +437,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
                     v2 = rs_buf_load16(fr, soff2, (uint32_t)arena_stride);
                 }
                 RS_STAMP(3);
+                RS_WSTAMP(0);
                 uint32_t o[NP];
                 if (HT_RS_EXPERIMENT == 1) {  // timing experiment (wrong results): no pixel arithmetic, one LDS read per row
 #pragma unroll
@@ -515,6 +531,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
 #pragma unroll
                 for (int q = 0; q < NP; q++) asm volatile("" ::"v"(o[q]));
                 RS_STAMP(4);
+                RS_WSTAMP(1);
 #endif
                 // Barriers inside the loop order LDS accesses only (fence restricted to the local address space: s_waitcnt lgkmcnt(0) + s_barrier).
                 // __syncthreads() also waits for vmcnt(0), i.e. for this iteration's global STORES to be acknowledged and for the prefetched
@@ -528,9 +545,14 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
                 if (f + 1 < f1) {
                     RS_LDS_BARRIER();  // every wave is done reading this frame's tile
                     RS_STAMP(5);
+                    RS_WSTAMP(2);
                     if (HT_RS_EXPERIMENT != 2) RS_TILE_TO_LDS();
                     RS_STORE_ROWS();
                     RS_LDS_BARRIER();
+                    RS_WSTAMP(3);
+#ifdef HT_RS_PHASES
+                    if (rs_iter == 2u && (threadIdx.x & 63u) == 0) g_rs_tw[rs_slot & 4095u][threadIdx.x >> 6][4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  // HW_ID
+#endif
                 } else {
                     RS_STORE_ROWS();
                     RS_STAMP(5);
@@ -905,9 +927,10 @@ extern "C" int ht_debug_rs_phases(unsigned long long *out16, int reset) {
     for (int sl = 0; sl < 16384; sl++)
         for (int it = 0; it < 8; it++) {
             const unsigned long long *t = h[sl][it];
-            if (!t[2] || !t[6] || t[6] < t[2] || t[6] - t[2] > (1ull << 24)) continue;  // empty or torn slot
-            for (int i = 3; i <= 6; i++)
-                if (t[i] >= t[i - 1]) out16[i] += t[i] - t[i - 1], out16[8 + i]++;
+            // empty or torn slot: different launches that hash to the same slot overwrite each other's stamps, and a mixture of two workgroups'
+            // stamps used to enter the means as a phase of 10^5 .. 10^7 cycles (round 3: "stores + barrier 17 534 cycles" was such a mean)
+            if (!t[2] || !t[6] || t[6] < t[2] || t[6] - t[2] > (1ull << 18) || t[3] < t[2] || t[4] < t[3] || t[5] < t[4] || t[6] < t[5]) continue;
+            for (int i = 3; i <= 6; i++) out16[i] += t[i] - t[i - 1], out16[8 + i]++;
             // setup of the workgroup: only if stamps 0, 1 and the first loop top are in order and close together (different launches
             // that hashed to the same slot overwrite each other's stamps)
             if (it == 0 && h[sl][0][0] && h[sl][0][0] <= h[sl][0][1] && h[sl][0][1] <= t[2] && t[2] - h[sl][0][0] < (1ull << 16)) {
@@ -926,9 +949,42 @@ extern "C" int ht_debug_rs_phases(unsigned long long *out16, int reset) {
         if (n) std::printf("  setup sub-phases (%llu samples): record %.0f, extents %.0f, addresses %.0f, load issue %.0f, tap tables %.0f, barrier %.0f cycles\n", n,
                            (double)sum[0] / n, (double)sum[1] / n, (double)sum[2] / n, (double)sum[3] / n, (double)sum[4] / n, (double)sum[5] / n);
     }
+    if (std::getenv("HT_RS_WAVESTAMPS")) {  // per-wave view of one frame iteration: do the four wavefronts of a workgroup reach the barrier together?
+        static unsigned long long w[4096][4][6];
+        if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_rs_tw), sizeof(w)) != hipSuccess) return 1;
+        double pix[4] = {}, wait1[4] = {}, mid[4] = {}, spread = 0, pixmax = 0, pixmin = 0;
+        unsigned long long n = 0, simd_hist[4][4] = {};
+        for (int sl = 0; sl < 4096; sl++) {
+            bool ok = true;
+            unsigned long long bmin = ~0ull, bmax = 0, pmn = ~0ull, pmx = 0;
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long *t = w[sl][k];
+                if (!t[0] || t[1] < t[0] || t[2] < t[1] || t[3] < t[2] || t[3] - t[0] > (1ull << 22)) ok = false;
+                bmin = std::min(bmin, t[1]), bmax = std::max(bmax, t[1]);
+                pmn = std::min(pmn, t[1] - t[0]), pmx = std::max(pmx, t[1] - t[0]);
+            }
+            if (!ok) continue;
+            n++;
+            spread += (double)(bmax - bmin), pixmax += (double)pmx, pixmin += (double)pmn;
+            for (int k = 0; k < 4; k++) {
+                const unsigned long long *t = w[sl][k];
+                pix[k] += (double)(t[1] - t[0]), wait1[k] += (double)(t[2] - t[1]), mid[k] += (double)(t[3] - t[2]);
+                simd_hist[k][(t[4] >> 4) & 3]++;
+            }
+        }
+        if (n) {
+            std::printf("  per-wave view (%llu workgroups, third frame iteration): pixel phase / wait at barrier 1 / tile write + stores + barrier 2, cycles\n", n);
+            for (int k = 0; k < 4; k++)
+                std::printf("    wave %d: %7.0f %7.0f %7.0f   SIMD histogram %llu %llu %llu %llu\n", k, pix[k] / n, wait1[k] / n, mid[k] / n, simd_hist[k][0], simd_hist[k][1],
+                            simd_hist[k][2], simd_hist[k][3]);
+            std::printf("    pixel phase of the fastest / slowest wave of a workgroup: %.0f / %.0f; spread of their arrival at barrier 1: %.0f cycles\n", pixmin / n, pixmax / n, spread / n);
+        }
+    }
     if (reset) {
         std::memset(h, 0, sizeof(h));
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_tl), h, sizeof(h)) != hipSuccess) return 1;
+        static unsigned long long wz[4096][4][6];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_tw), wz, sizeof(wz)) != hipSuccess) return 1;
     }
     return 0;
 }

@@ -396,6 +396,10 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
             const RsTap *ct = &s_col[min(cbase + k, ncols - 1)];
             ia[k] = ct->a - xa, ctf[k] = (float)ct->t;
         }
+        if (HT_RS_EXPERIMENT == 4) {  // timing experiment (wrong results): conflict-free tap addresses — what would halving the LDS cycles buy?
+#pragma unroll
+            for (int k = 0; k < 4; k++) ia[k] = (tid & 31) * 4 + ((tid >> 5) & 1) * 1280 + k * 160 * 2;
+        }
         // the right taps are read at p + 1 — with a "1" the optimiser cannot see: hipcc otherwise fuses p[0] and p[1] into ONE
         // ds_read_u16 at an arbitrary byte address (see rs_pixel_f64)
         uint32_t one = 1u;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
             for (int q = 0; q < NP; q++) {
                 const int y = yt + 16 * q;
                 const RsTap *ry = &s_row[min(y - Y0, nrows - 1)];
-                roff[q] = (uint32_t)((ry->a - ya) * RS_SP);
+                roff[q] = HT_RS_EXPERIMENT == 4 ? (uint32_t)(q * 3 * RS_SP) : (uint32_t)((ry->a - ya) * RS_SP);
                 rtf[q] = (float)ry->t;
                 rv[q] = y < dh;  // a drawn row (pxmask is 0 where the thread has no drawn column)
                 st[q] = y < ch && x0 < dst_stride;

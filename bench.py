@@ -257,7 +257,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
         total = nf * world
         f0 = rank * nf
     nf_max = -(-total // world)
-    uniq = min(a.unique or (12 if name == "c4" else 256), nf)
+    uniq = min(a.unique or (128 if name == "c4" else 256), nf)  # C4: every frame of the per-GPU batch is distinct (round 2 tiled 12 unique frames); the 1024-frame strong-scaling batch repeats the 128
     # frame g of the job is synthetic frame g mod uniq' of the N/S/F mix, seeded per rank
     base = synth.mixed_batch(uniq, W, H, seed0=1234 + 1000 * rank)
     dev_uniq = torch.from_numpy(base).cuda()

@@ -107,6 +107,19 @@ def test_pyramid_planes_vs_oracle(ctx, w, h):
     _check_pyramid(ctx, w, h)
 
 
+def _random_sizes(n, seed):
+    rng = np.random.RandomState(seed)
+    return [(int(rng.randint(24, 1100)), int(rng.randint(24, 800))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("w,h", _random_sizes(16, 20260921) + [(1023, 65), (65, 799), (129, 513), (512, 512), (2048, 64)])
+def test_pyramid_planes_random_geometries(ctx, w, h):
+    """k_resample's flat frame loop is specialised on the pass count of a tile (1-4) and on the exact-2:1 box mode, masks the pixels
+    outside the drawn rect byte by byte and reads clamped taps for undrawn pixels: seeded random and extreme aspect ratios hit every
+    combination of partial tiles, partial passes, odd / even parents and narrow last columns.  All planes of an N, an S and an F frame."""
+    _check_pyramid(ctx, w, h)
+
+
 @pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (38, 30)])
 def test_pyramid_without_tail_kernel(w, h, monkeypatch):
     """The last (tiny) generations are built by k_resample_tail by default; with HT_DEBUG_RS_NOTAIL every generation goes

@@ -40,7 +40,7 @@ def test_c2_batch_every_frame_vs_oracle(cascade):
 
 
 def test_c4_batch_shape_every_frame_vs_oracle(cascade):
-    """C4 per-GPU shape: 128 x 1280x720 built from the 12 unique frames of the bench (tile count, XCD ordering, survivor
+    """C4 per-GPU shape: 128 x 1280x720 built from the first 12 of the bench's 128 distinct frames (tile count, XCD ordering, survivor
     queue at 129 M windows): every frame's hits and the per-stage window counts == the oracle's."""
     w, h, n, uniq = 1280, 720, 128, 12
     base = synth.mixed_batch(uniq, w, h, seed0=1234)
@@ -78,7 +78,7 @@ def test_c4_batch_shape_every_frame_vs_oracle(cascade):
 def test_c4_strong_shape_1024_frames_on_one_gpu(cascade):
     """The `c4_strong` sub-record of the bench line: all 1024 x 1280x720 frames of BASELINE.json configs[3] in ONE batch on one GPU
     (15 x the tile count, survivor queue and hit volume of the 128-frame shape; 1.03 G windows): every frame's raw hits — indices and
-    binary64 confidence bits — and the per-stage window counts == the oracle's.  Frames are the bench's 12 unique frames tiled."""
+    binary64 confidence bits — and the per-stage window counts == the oracle's.  Frames are the first 12 of the bench's distinct frames, tiled."""
     from hipmem import DeviceArray
 
     w, h, n, uniq = 1280, 720, 1024, 12

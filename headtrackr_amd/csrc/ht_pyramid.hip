@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
     uint32_t rs_iter = 0;
 #endif
     RS_STAMP(0);
-    const HtResampleJob &J = tiles[blk];
+    const HtResampleJob J = tiles[blk];  // by value: the whole record in a few wide scalar loads, ONE round trip (as a reference its fields were fetched piecemeal, eight dependent s_load round trips along the prologue)
     const uint32_t f0 = gidx * group_frames, f1 = min(f0 + group_frames, nframes);
     const int tid = (int)threadIdx.x;
     const int np = (int)J.np;
@@ -590,20 +590,24 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
     }
     // nothing drawn in this tile (transparent black), or a source span larger than the LDS window (ratios > 2.3: the
     // last 1-3 pixel levels): taps straight from HBM
+    const HtResampleJob &Jm = tiles[blk];  // this (rare) path reads the record from memory field by field: the by-value copy above would
+                                             // keep 22 scalar registers alive across its binary64 loop and push it into scratch
     RsTap cx[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) cx[k] = rs_tap(min(x0 + k, X0 + max(ncols, 1) - 1), J.rx, J.sw, J.sx);
+    for (int k = 0; k < 4; k++) cx[k] = rs_tap(min(x0 + k, X0 + max(ncols, 1) - 1), Jm.rx, Jm.sw, Jm.sx);
     for (uint32_t f = f0; f < f1; f++, frame += arena_stride) {
-        const uint8_t *src = frame + J.src_off;
+        const uint8_t *src = frame + Jm.src_off;
+        int ytl = yt;
+        asm volatile("" : "+v"(ytl));  // opaque per frame: the row taps and addresses of all four passes are loop invariants, and hoisted they do not fit the register budget
 #pragma unroll
         for (int q = 0; q < RPT; q++) {
-            const int y = yt + 16 * q;
+            const int y = ytl + 16 * q;
             uint32_t o = 0;
-            if (drawn && q < np && y < J.dh && npx > 0) {
-                const RsTap ry = rs_tap(y, J.ry, J.sh, J.sy);
-                o = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * J.src_stride, src + (size_t)ry.b * J.src_stride, cx, ry, 0, npx);
+            if (drawn && q < np && y < Jm.dh && npx > 0) {
+                const RsTap ry = rs_tap(y, Jm.ry, Jm.sh, Jm.sy);
+                o = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * Jm.src_stride, src + (size_t)ry.b * Jm.src_stride, cx, ry, 0, npx);
             }
-            if (q < np && y < J.ch && x0 < J.dst_stride) *reinterpret_cast<uint32_t *>(frame + J.dst_off + (size_t)y * J.dst_stride + x0) = o;
+            if (q < np && y < Jm.ch && x0 < Jm.dst_stride) *reinterpret_cast<uint32_t *>(frame + Jm.dst_off + (size_t)y * Jm.dst_stride + x0) = o;
         }
     }
 }

@@ -478,7 +478,7 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
                 for (int x = 0; x < nbx; x++) {
                     HtResampleJob t = j;
                     t.bx = (uint16_t)x, t.pass0 = (uint16_t)pass0, t.np = (uint16_t)np;
-                    // bit 0: exact 2:1 in both directions (2x2 box mean in integers, see rs_pixels4_lds); HT_DEBUG_RS_NOFAST=1 keeps
+                    // bit 0: exact 2:1 in both directions (2x2 box mean, see the BOX rows of k_resample); HT_DEBUG_RS_NOFAST=1 keeps
                     // every pixel on the declared binary64 sequence (A/B and cross-check)
                     t.pad = getenv("HT_DEBUG_RS_NOFAST") ? 2 : (uint16_t)((j.dw > 0 && j.sw == 2 * j.dw && j.sh == 2 * j.dh) ? 1 : 0);
                     const int X0 = 64 * x, Y0 = 16 * pass0, ncols = std::min(64, j.dw - X0), nrows = std::min(16 * np, j.dh - Y0);

@@ -180,17 +180,6 @@ __device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap (&cx)
     return o;
 }
 
-// LDS variant.  Two facts of the declared resampler make the addressing trivial: b == a + 1 unless the coordinate was
-// clamped to the last source sample, and then its weight t is exactly 0, so ANY finite neighbour gives the same rounded
-// sum (x * 0 = +0 for every byte x).  The four taps of a pixel are therefore p[0], p[1], p[pitch], p[pitch + 1] from one
-// address (ds_read_u8 with immediate offsets) whatever the clamping; s_src carries one spare row for the p[pitch] read
-// of the last staged row.  Store: round half to even via the 2^52 + 2^51 add (values are within [0, 255]).
-// p = address of the left taps, p1 = address of the right taps (= p + 1, but derived from a separately "laundered" index: hipcc
-// otherwise fuses p[0] and p[1] into ONE ds_read_u16 at an arbitrary byte address, and gfx950's LDS serves a misaligned
-// access lane by lane — 64 instead of 2 cycles per wave, measured with tools/micro/lds_unaligned_bench.hip; the first build of
-// the binary32 path ran 2.3x slower than the binary64 one because of it)
-// the right tap of a pair as a relaxed workgroup-scope atomic load: still a plain ds_read_u8 (with the immediate offset folded), but one the
-// optimiser does not fuse with its left neighbour into a ds_read_u16 at an arbitrary byte address
 // workgroup barrier that orders LDS accesses only: global loads / stores stay in flight across it
 #define RS_LDS_BARRIER()                                                     \
     do {                                                                     \
@@ -198,7 +187,18 @@ __device__ __forceinline__ uint32_t rs_pixels4(PTR r0, PTR r1, const RsTap (&cx)
         __builtin_amdgcn_s_barrier();                                        \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");      \
     } while (0)
+// The right tap of a pair as a relaxed workgroup-scope atomic load: still a plain ds_read_u8 (with the immediate offset folded), but one
+// the optimiser does not fuse with its left neighbour.  hipcc otherwise turns p[0], p[1] into ONE ds_read_u16 at an arbitrary byte
+// address, and gfx950's LDS serves a misaligned access lane by lane — 64 instead of 2 cycles per wave, measured with
+// tools/micro/lds_unaligned_bench.hip (the first build of the binary32 path ran 2.3x slower than the binary64 one because of it).
 #define RS_LD1(ptr_) __hip_atomic_load((ptr_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)
+
+// LDS variant of a pixel, declared binary64 sequence.  Two facts of the declared resampler make the addressing trivial: b == a + 1 unless
+// the coordinate was clamped to the last source sample, and then its weight t is exactly 0, so ANY finite neighbour gives the same rounded
+// sum (x * 0 = +0 for every byte x).  The four taps of a pixel are therefore p[0], p[1], p[pitch], p[pitch + 1] from one address
+// (ds_read_u8 with immediate offsets) whatever the clamping; s_src carries one spare row for the p[pitch] read of the last staged row.
+// Store: round half to even via the 2^52 + 2^51 add (values are within [0, 255]).  p = address of the left taps, p1 = address of the
+// right taps (= p + 1 through a value the optimiser cannot see, for the reason given at RS_LD1).
 __device__ __forceinline__ uint32_t rs_pixel_f64(const uint8_t *p, const uint8_t *p1, double cu, double ct, double ru, double rt) {
     const double top = __dadd_rn(__dmul_rn((double)p[0], cu), __dmul_rn((double)p1[0], ct));
     const double bot = __dadd_rn(__dmul_rn((double)p[RS_SP], cu), __dmul_rn((double)p1[RS_SP], ct));

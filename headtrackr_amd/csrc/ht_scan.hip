@@ -369,7 +369,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                         const uint32_t pos = bu * 64u + lane;
                         valid[u] = bu < b_hi && pos < n_in;
                         id[u] = valid[u] ? pos : 0u;
-                        yy[u] = __umul24(id[u], S.div_magic) >> 20;  // 24-bit multiplies: v_mul_lo_u32 is quarter rate (id < 2^11, magic < 2^18)
+                        yy[u] = __umul24(id[u], S.div_magic) >> 20;  // 24-bit multiplies (id < 2^11, magic < 2^18); v_mul_lo_u32 measures at the same 4 cycles per wave64 (tools/micro/valu_rate_bench.hip)
                         xx[u] = id[u] - __umul24(yy[u], (uint32_t)S.tw2);
                         valid[u] = valid[u] && xx[u] < (uint32_t)tw;
                     }

@@ -34,7 +34,7 @@ for pair in "tltl gpu_tile_timeline tile_timeline" "rsph gpu_rs_phases rs_phases
   if python tools/build_alt.py --check $1 > /dev/null; then
     cp alt/$1.so $LIB
     for wl in c2 c4; do
-      timeout 300 python tools/$2.py $wl > $OUT/$3_$wl.txt 2> $OUT/$3_$wl.err || { echo "$2 $wl FAILED (see $OUT/$3_$wl.err)"; rm -f $OUT/$3_$wl.txt; }
+      HT_RS_WAVESTAMPS=1 timeout 300 python tools/$2.py $wl > $OUT/$3_$wl.txt 2> $OUT/$3_$wl.err || { echo "$2 $wl FAILED (see $OUT/$3_$wl.err)"; rm -f $OUT/$3_$wl.txt; }
     done
     cp /tmp/final_base.so $LIB
   else

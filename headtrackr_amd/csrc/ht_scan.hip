@@ -868,7 +868,18 @@ __device__ __forceinline__ long long wave_sum_i64_dpp(long long v) {
     return l0 + (l1 << 21) + (l2 << 42) - (64ll << 40);
 }
 
-__global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_t *__restrict__ arena, uint64_t arena_stride,
+#ifdef HT_DEEP_TIMELINE  // tools/gpu_deep_timeline.py: shader-clock stamps per wavefront of k_scan_deep_lds (first window of each wavefront)
+__device__ unsigned long long g_deep_tl[8192][8];  // entry, table copied, patch loaded, window done, last stage run, exact-sum start
+#define DL_STAMP(i)                                                                                                  \
+    do {                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+        if ((threadIdx.x & 63u) == 0 && dl_first) g_deep_tl[(blockIdx.x * DEEPL_WAVES + (threadIdx.x >> 6)) & 8191u][i] = __builtin_readcyclecounter(); \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
+#else
+#define DL_STAMP(i)
+#endif
+__global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k_scan_deep_lds(const uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                                    const HtDevLevel *__restrict__ levels, int next,
                                                                    const HtPackedFeature *__restrict__ packed, uint32_t packed_count,
                                                                    uint32_t packed_first, const HtDevStage *__restrict__ stages, int nstages,
@@ -882,51 +893,59 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
     uint8_t *per_wave = reinterpret_cast<uint8_t *>(s_stages + 64);
     const uint32_t n = min(ctr->nqueue, queue_cap);
     if (blockIdx.x * DEEPL_WAVES >= n) return;  // nothing for this workgroup: skip the table copy
+#ifdef HT_DEEP_TIMELINE
+    bool dl_first = true;
+#endif
+    DL_STAMP(0);
     for (uint32_t i = threadIdx.x; i < packed_count * 2u; i += blockDim.x) tab[i] = reinterpret_cast<const uint4 *>(packed)[i];
     for (uint32_t i = threadIdx.x; i < (uint32_t)nstages * (sizeof(HtDevStage) / 16); i += blockDim.x)
         reinterpret_cast<uint4 *>(s_stages)[i] = reinterpret_cast<const uint4 *>(stages)[i];
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    DL_STAMP(1);
+    const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the patch address, the queue index and the statistics row become scalar registers
     uint8_t *patch = per_wave + wv * (PATCH_BYTES + 512);
     double *sel_buf = reinterpret_cast<double *>(patch + PATCH_BYTES);
     const uint32_t wave = blockIdx.x * DEEPL_WAVES + wv, nwaves = gridDim.x * DEEPL_WAVES;
     unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
     for (uint32_t e = wave; e < n; e += nwaves) {
         const HtQueueEntry ent = queue[e];
+        uint32_t ln = lane;  // the gathers' index arithmetic from an opaque lane number: as loop invariants it would be hoisted out of the window
+        asm volatile("" : "+v"(ln));  // loop and held (spilled, at this budget) across the stage passes
         HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
                      (uint32_t)ent.y)
         {
             uint32_t pa[5], pb[3], pc = 0;
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const uint32_t i = lane + 64u * k, r = i / 12u, c2 = (i - r * 12u) * 2u;
+                const uint32_t i = ln + 64u * k, r = i / 12u, c2 = (i - r * 12u) * 2u;
                 pa[k] = 0;
                 if (i < 288u) pa[k] = *reinterpret_cast<const uint16_t *>(fb + o0 + r * (uint32_t)s0 + c2);
             }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const uint32_t i = lane + 64u * k, r = i / 12u, c = i - r * 12u;
+                const uint32_t i = ln + 64u * k, r = i / 12u, c = i - r * 12u;
                 pb[k] = 0;
                 if (i < 144u) pb[k] = fb[o1 + r * (uint32_t)s1 + c];
             }
-            if (lane < 36u) {
-                const uint32_t r = lane / 6u, c = lane - r * 6u;
+            if (ln < 36u) {
+                const uint32_t r = ln / 6u, c = ln - r * 6u;
                 pc = fb[o2 + r * (uint32_t)s2 + c];
             }
 #pragma unroll
             for (int k = 0; k < 5; k++) {
-                const uint32_t i = lane + 64u * k;
+                const uint32_t i = ln + 64u * k;
                 if (i < 288u) *reinterpret_cast<uint16_t *>(&patch[2u * i]) = (uint16_t)pa[k];
             }
 #pragma unroll
             for (int k = 0; k < 3; k++) {
-                const uint32_t i = lane + 64u * k;
+                const uint32_t i = ln + 64u * k;
                 if (i < 144u) patch[PATCH1 + i] = (uint8_t)pb[k];
             }
-            if (lane < 36u) patch[PATCH2 + lane] = (uint8_t)pc;
+            if (ln < 36u) patch[PATCH2 + ln] = (uint8_t)pc;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        DL_STAMP(2);
         bool alive = true;
         double conf = 0.0;
         for (int j = (int)ent.pad; j < nstages; j++) {
@@ -934,40 +953,83 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
             const uint32_t base = st.first - packed_first;  // index of the stage's first record in the LDS table
             if (lane == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
             long long acc = 0;
-            for (uint32_t k = lane; k < st.count; k += 64) {
-                const uint4 A = tab[(base + k) * 2u], Bq = tab[(base + k) * 2u + 1u];
-                acc += packed_fire(patch, A, Bq.x) ? (long long)(int32_t)Bq.z : (long long)(int32_t)Bq.y;
+            // The LAST stage keeps what every lane's features selected (alpha * 1e8, one register per 64-feature chunk, up to KEEP chunks):
+            // a window that passes it needs the sequential binary64 sum of exactly these alphas for its confidence, and re-evaluating the
+            // fires chunk by chunk in front of every 64 adds was a third of that sum's time.
+            constexpr int KEEP = 10;
+            int32_t kept[KEEP];
+            const bool keep = (j == nstages - 1) && st.count <= 64u * KEEP;
+            if (keep) {
+#pragma unroll
+                for (int cki = 0; cki < KEEP; cki++) {
+                    const uint32_t k = 64u * cki + lane;
+                    kept[cki] = 0;
+                    if (64u * cki < st.count && k < st.count) {  // first test is wave-uniform
+                        const uint4 A = tab[(base + k) * 2u], Bq = tab[(base + k) * 2u + 1u];
+                        kept[cki] = packed_fire(patch, A, Bq.x) ? (int32_t)Bq.z : (int32_t)Bq.y;
+                        acc += (long long)kept[cki];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);  // one chunk at a time: interleaved, ten chunks' records and pixels do not fit the register budget
+                }
+            } else {
+                for (uint32_t k = lane; k < st.count; k += 64) {
+                    const uint4 A = tab[(base + k) * 2u], Bq = tab[(base + k) * 2u + 1u];
+                    acc += packed_fire(patch, A, Bq.x) ? (long long)(int32_t)Bq.z : (long long)(int32_t)Bq.y;
+                }
             }
             const long long Ssum = wave_sum_i64_dpp(acc);
             if (Ssum < st.thri) {  // sum < threshold decided exactly, independent of summation order
                 alive = false;
                 break;
             }
+#ifdef HT_DEEP_TIMELINE
+            if (lane == 0 && dl_first) g_deep_tl[(blockIdx.x * DEEPL_WAVES + wv) & 8191u][4] = (unsigned long long)j;
+#endif
             if (Ssum == st.thri || j == nstages - 1 || force_exact) {
-                // sequential binary64 sum in the reference's order (ccv.js:186-221): every lane parks the alpha its feature
-                // selected in LDS, then the wave adds them in feature order from broadcast reads (the loads do not depend
-                // on the running sum, so only the adds form the chain)
+                DL_STAMP(5);
+                // sequential binary64 sum in the reference's order (ccv.js:186-221): every lane parks the alpha its feature selected in LDS,
+                // then the wave adds them in feature order from broadcast reads.  Only the adds form the chain: the reads of the next 8
+                // alphas are in flight while 8 are added, and the last stage's selected alphas were kept in registers by its integer pass
+                // (tools/gpu_deep_timeline.py: this sum was 26 k of a full survivor's 63 k cycles with 8 reads, then 8 adds, per step and
+                // the fires recomputed in between).  Lanes past the stage's end park +0.0: adding +0.0 never changes a binary64 sum
+                // that is not -0.0, and the sum starts at +0.0 — so every chunk is 64 adds, no trip counts.
                 double sum = 0.0;
-                for (uint32_t kb = 0; kb < st.count; kb += 64) {
-                    const uint32_t k = kb + lane;
+                auto sel_of = [&](uint32_t k) -> double {
                     double sel = 0.0;
                     if (k < st.count) {
                         const uint4 A = tab[(base + k) * 2u], Bq = tab[(base + k) * 2u + 1u];
                         const int32_t ai = packed_fire(patch, A, Bq.x) ? (int32_t)Bq.z : (int32_t)Bq.y;
                         sel = (double)ai / 1e8;  // == alpha exactly (checked when the table was packed)
                     }
-                    sel_buf[lane] = sel;  // lanes >= nn park 0.0: adding +0.0 never changes a binary64 sum that is not -0.0
+                    return sel;
+                };
+                auto add64 = [&](double sel) {  // sum += sel[lane 0] + ... + sel[lane 63], in lane order
+                    sel_buf[lane] = sel;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
-                    const uint32_t nn = min(64u, st.count - kb);
-                    uint32_t t = 0;
-                    for (; t + 8 <= nn; t += 8) {
-                        const double v0 = sel_buf[t], v1 = sel_buf[t + 1], v2 = sel_buf[t + 2], v3 = sel_buf[t + 3];
-                        const double v4 = sel_buf[t + 4], v5 = sel_buf[t + 5], v6 = sel_buf[t + 6], v7 = sel_buf[t + 7];
-                        sum = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(sum, v0), v1), v2), v3), v4), v5), v6), v7);
+                    double g[8], h[8];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) g[u] = sel_buf[u];
+#pragma unroll
+                    for (int grp = 0; grp < 8; grp++) {
+                        if (grp < 7) {
+#pragma unroll
+                            for (int u = 0; u < 8; u++) h[u] = sel_buf[8 * (grp + 1) + u];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < 8; u++) sum = __dadd_rn(sum, g[u]);
+#pragma unroll
+                        for (int u = 0; u < 8; u++) g[u] = h[u];
                     }
-                    for (; t < nn; t++) sum = __dadd_rn(sum, sel_buf[t]);
-                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_wave_barrier();  // every lane has read the buffer before the next chunk overwrites it
+                };
+                if (keep) {
+#pragma unroll
+                    for (int cki = 0; cki < KEEP; cki++)
+                        if (64u * cki < st.count) add64((double)kept[cki] / 1e8);  // lanes past the stage's end kept 0 -> +0.0
+                } else {
+                    for (uint32_t kb = 0; kb < st.count; kb += 64) add64(sel_of(kb + lane));
                 }
                 if (sum < st.threshold) {  // ccv.js:222
                     alive = false;
@@ -992,6 +1054,10 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES) void k_scan_deep_lds(const uint8_
                 hits[pos] = h;
             }
         }
+        DL_STAMP(3);
+#ifdef HT_DEEP_TIMELINE
+        dl_first = false;
+#endif
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -1309,3 +1375,15 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
     }
     return HT_OK;
 }
+
+#ifdef HT_DEEP_TIMELINE
+extern "C" int ht_debug_deep_timeline(unsigned long long *out, int nmax) {  // out[nmax][8]
+    static unsigned long long h[8192][8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_deep_tl), sizeof(h)) != hipSuccess) return -1;
+    const int n = std::min(nmax, 8192);
+    std::memcpy(out, h, (size_t)n * 8 * sizeof(unsigned long long));
+    std::memset(h, 0, sizeof(h));
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_deep_tl), h, sizeof(h)) != hipSuccess) return -1;
+    return n;
+}
+#endif

@@ -239,6 +239,7 @@ constexpr float RS_EPS = 1.0f / 8192.0f;
 #endif
 #if defined(HT_RS_PHASES)  // tools/gpu_rs_phases.py: shader-clock stamps of every phase of every frame iteration, plain stores into per-workgroup slots
 __device__ unsigned long long g_rs_tl[16384][8][8];  // [slot][frame iteration & 7][stamp]
+__device__ unsigned long long g_rs_launch[1024][4];  // per launch (keyed by its tiles per frame): workgroups, sum of workgroup lifetimes
 __device__ unsigned long long g_rs_tw[4096][4][6];   // per WAVE, third frame iteration of a workgroup: pixel start, pixel end, after barrier 1, after barrier 2, HW_ID
 #define RS_WSTAMP(i)                                                                                                                  \
     do {                                                                                                                              \
@@ -305,6 +306,17 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
     uint32_t rs_iter = 0;
 #endif
     RS_STAMP(0);
+#ifdef HT_RS_PHASES
+    const unsigned long long rs_t_entry = __builtin_readcyclecounter();
+    auto rs_exit = [&]() {
+        if (threadIdx.x == 0) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            unsigned long long *L = g_rs_launch[blocks_per_frame & 1023u];
+            atomicAdd(&L[0], 1ull);
+            atomicAdd(&L[1], now - rs_t_entry);
+        }
+    };
+#endif
     const HtResampleJob J = tiles[blk];  // by value: the whole record in a few wide scalar loads, ONE round trip (as a reference its fields were fetched piecemeal, eight dependent s_load round trips along the prologue)
     const uint32_t f0 = gidx * group_frames, f1 = min(f0 + group_frames, nframes);
     const int tid = (int)threadIdx.x;
@@ -586,6 +598,9 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         }
 #undef RS_TILE_TO_LDS
 #undef RS_FRAME_RSRC
+#ifdef HT_RS_PHASES
+        rs_exit();
+#endif
         return;
     }
     // nothing drawn in this tile (transparent black), or a source span larger than the LDS window (ratios > 2.3: the
@@ -871,8 +886,9 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         HT_HIP(c, hipGetLastError());
     }
     const size_t regular_end = c->tail_first_gen > 0 ? (size_t)c->tail_first_gen : c->h_gens.size();
+    static const int dbg_maxgen = getenv("HT_DEBUG_RS_MAXGEN") ? atoi(getenv("HT_DEBUG_RS_MAXGEN")) : 1 << 30;  // measurement knob (results stale): what do the later generations cost the wall clock?
     for (size_t g = 1; g < regular_end; g++) {
-        if (c->gen_blocks[g] == 0) continue;
+        if (c->gen_blocks[g] == 0 || (int)g > dbg_maxgen) continue;
         char gname[24];
         std::snprintf(gname, sizeof(gname), "resample_g%d", (int)g);
         HtProfScope ps(c, getenv("HT_DEBUG_RS_GENNAMES") ? gname : "resample");  // measurement knob: device time per pyramid generation
@@ -893,7 +909,7 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
             if (st != HT_OK) return st;
         }
     }
-    if (c->tail_first_gen > 0) {
+    if (c->tail_first_gen > 0 && c->tail_first_gen <= dbg_maxgen) {
         HtProfScope ps(c, getenv("HT_DEBUG_RS_GENNAMES") ? "resample_tail" : "resample");
         if (c->tail_table)
             hipLaunchKernelGGL(k_resample_tail, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
@@ -957,6 +973,12 @@ extern "C" int ht_debug_rs_phases(unsigned long long *out16, int reset) {
         if (n) std::printf("  setup sub-phases (%llu samples): record %.0f, extents %.0f, addresses %.0f, load issue %.0f, tap tables %.0f, barrier %.0f cycles\n", n,
                            (double)sum[0] / n, (double)sum[1] / n, (double)sum[2] / n, (double)sum[3] / n, (double)sum[4] / n, (double)sum[5] / n);
     }
+    if (std::getenv("HT_RS_LAUNCHES")) {  // per launch: how long does a workgroup live?
+        static unsigned long long L[1024][4];
+        if (hipMemcpyFromSymbol(L, HIP_SYMBOL(g_rs_launch), sizeof(L)) != hipSuccess) return 1;
+        for (int k = 0; k < 1024; k++)
+            if (L[k][0]) std::printf("  launches with %4d tiles per frame: %6llu workgroups (LDS path), mean life %7.0f cycles\n", k, L[k][0], (double)L[k][1] / (double)L[k][0]);
+    }
     if (std::getenv("HT_RS_WAVESTAMPS")) {  // per-wave view of one frame iteration: do the four wavefronts of a workgroup reach the barrier together?
         static unsigned long long w[4096][4][6];
         if (hipMemcpyFromSymbol(w, HIP_SYMBOL(g_rs_tw), sizeof(w)) != hipSuccess) return 1;
@@ -993,6 +1015,9 @@ extern "C" int ht_debug_rs_phases(unsigned long long *out16, int reset) {
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_tl), h, sizeof(h)) != hipSuccess) return 1;
         static unsigned long long wz[4096][4][6];
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_tw), wz, sizeof(wz)) != hipSuccess) return 1;
+        static unsigned long long lz[1024][4];
+        for (int k = 0; k < 1024; k++) lz[k][0] = lz[k][1] = lz[k][3] = 0, lz[k][2] = ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rs_launch), lz, sizeof(lz)) != hipSuccess) return 1;
     }
     return 0;
 }

@@ -24,7 +24,7 @@ lib.ht_debug_rs_phases.argtypes = [C.c_void_p, C.c_int]
 raw = np.zeros(16, dtype=np.uint64)
 c.detect_raw(frames, cap=1 << 18)
 lib.ht_debug_rs_phases(raw.ctypes.data, 1)
-for rep in range(3):
+for rep in range(1 if os.environ.get("HT_RS_LAUNCHES") else 3):  # one batch when the per-launch spans are asked for: they are first entry -> last exit per key
     c.detect_raw(frames, cap=1 << 18)
 lib.ht_debug_rs_phases(raw.ctypes.data, 1)
 cyc, cnt = raw[:8].astype(np.float64), raw[8:].astype(np.float64)

@@ -65,7 +65,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
     ap.add_argument("--pipeline", type=int, default=0, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn; "
-                    "0 = auto: 3 while one batch (frames + pyramid) fits the 256 MB Infinity Cache, else 2 (measured: 320x240 x 256 best at 3, 1280x720 x 128 at 2)")
+                    "0 = auto: 2 (round 3, with the re-enqueue inside the collect call: 320x240 x 256 runs 985 k frames/s at 2 and 982 k at 3 over 1000 steps, "
+                    "and a 20-step block pays one batch less of fill: 921-944 k at 2, 889-899 k at 3; 1280x720 x 128 was best at 2 already)")
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steady-state work before the warm-up steps (0 for profiler runs)")
     ap.add_argument("--no-sub", action="store_true", help="only the primary workload (no c4 / c3 sub-records)")
     ap.add_argument("--no-requeue", action="store_true", help="A/B: enqueue a context's next batch only after its results were post-processed")
@@ -264,8 +265,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     idx = torch.arange(nf, device="cuda") % uniq
     dev = dev_uniq[idx].contiguous() if nf != uniq else dev_uniq  # resident in HBM before the timed region
     del dev_uniq
-    batch_bytes = nf * (W * H * 4 + int(1.45 * W * H))  # RGBA frames + ~1.43 gray bytes of pyramid planes per pixel (P / (W H))
-    depth = a.pipeline if a.pipeline > 0 else (3 if batch_bytes <= (256 << 20) else 2)
+    depth = a.pipeline if a.pipeline > 0 else 2  # profiles/r03_pipeline_depth.txt
     ctxs = []
     for _ in range(depth):
         cx = Context(device=local)
@@ -719,7 +719,7 @@ def stream_bench(env, a, feeds=1, steps=300, warm_cycles=1, cpu_seconds=0.0):
 
 def js_host_bench(seconds=2.0):
     """tests/js/bench_host.js on this GPU: detect frames/s at the C2 shape from Node — ccv.detect_objects_batch on host frames (PCIe
-    every call) and ccv.DeviceBatch (frames resident in HBM, enqueue / collect-best / re-enqueue over 3 contexts: this file's
+    every call) and ccv.DeviceBatch (frames resident in HBM, enqueue / collect-best / re-enqueue over 2 contexts: this file's
     headline loop, driven from JavaScript) — and the per-call latency of the drop-in facetrackr.Tracker.track() at 320x240, next to
     the unmodified reference JS on the same frames.  None when node or the addon is missing."""
     from headtrackr_amd import synth

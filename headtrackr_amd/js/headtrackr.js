@@ -347,7 +347,7 @@ headtrackr.ccv.DeviceBatch = function (w, h, n, opts) {
   opts = opts || {};
   const cascade = opts.cascade || headtrackr.cascade, interval = opts.interval === undefined ? 5 : opts.interval;
   const device = opts.device === undefined ? (headtrackr.device | 0) : opts.device;
-  const depth = Math.max(1, opts.depth || 3), sets = Math.max(1, opts.sets || 1);
+  const depth = Math.max(1, opts.depth || 2), sets = Math.max(1, opts.sets || 1);
   const A = addon(), fbytes = w * h * 4, setBytes = n * fbytes;
   const blob = pack.packCascade(cascade), dims = levelDims(w, h, cascade, interval);
   const ctxs = [];

@@ -4,7 +4,7 @@
  *     node tests/js/bench_host.js <seconds> <c2_frames.raw> <n> <track_frames.raw> <nt>     -> one JSON line
  *   c2_frames.raw     n RGBA frames of 320x240 (the C2 mix): detect throughput from Node
  *       batch_host    ccv.detect_objects_batch on host frames (pageable Uint8Array -> PCIe every call), full result lists
- *       batch_device  ccv.DeviceBatch.detectBest: frames resident in HBM, 3 batches in flight (enqueue / collect-best / re-enqueue),
+ *       batch_device  ccv.DeviceBatch.detectBest: frames resident in HBM, 2 batches in flight (enqueue / collect-best / re-enqueue),
  *                     best face per frame — the loop bench.py's headline times, from JavaScript
  *   track_frames.raw  nt RGBA frames of 320x240 with one drifting face: per-call latency of the DROP-IN
  *                     facetrackr.Tracker.track() (facetrackr.js:67-126; the author's budget is ~15 ms per step, main.js:51,163):
@@ -40,7 +40,7 @@ const out = { node: process.version, cpus: require('os').cpus().length, cpu_mode
       what: 'ccv.detect_objects_batch(frames, n, w, h): pageable host frames cross PCIe every call; full grouped rect lists in JS' };
   }
   {
-    const b = new headtrackr.ccv.DeviceBatch(W, H, n, { depth: 3 });
+    const b = new headtrackr.ccv.DeviceBatch(W, H, n, { depth: +(process.env.HT_JS_DEPTH || 2) });
     b.upload(frames);
     b.detectBest(12); /* warm-up */
     let batches = 0, r = null;
@@ -51,7 +51,7 @@ const out = { node: process.version, cpus: require('os').cpus().length, cpu_mode
     for (let f = 0; f < n; f++) if (r.best[6 * f + 5] > 0) faces++;
     out.batch_device = { frames_per_s: +(batches * n / dt).toFixed(1), ms_per_batch: +(dt / batches * 1e3).toFixed(4), batch: n, batches: batches, in_flight: b.depth,
       frames_with_faces: faces, hits_last_batch: r.hits,
-      what: 'ccv.DeviceBatch.detectBest: frames resident in HBM, detectEnqueue + collectBest(requeue) over 3 contexts; best face per frame' };
+      what: 'ccv.DeviceBatch.detectBest: frames resident in HBM, detectEnqueue + collectBest(requeue) over ' + b.depth + ' contexts; best face per frame' };
     b.destroy();
   }
 

@@ -306,6 +306,9 @@ struct ht_ctx {
     unsigned long long h_stage_in[64] = {0};   // windows that entered stage j ([nstages] = full survivors), last collected batch
     std::vector<ht_hit> h_collect_hits;        // ht_detect_collect_best: sorted raw hits of the last batch
     std::vector<uint32_t> h_collect_counts;    // ... and their per-frame counts
+    std::vector<ht_hit> h_raw_hits;            // ht_detect_collect: the batch's raw hits in arrival order (scratch, kept between calls)
+    std::vector<ht_hit> h_ordered_hits;        // ... and in emission order when the caller's buffer cannot take them directly
+    std::vector<uint32_t> h_frame_start;       // ... bucket offsets of the counting sort by frame
     bool stats_enqueued = false;
     bool enqueued = false;
 

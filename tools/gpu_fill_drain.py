@@ -9,6 +9,8 @@ from headtrackr_amd.api import Context
 
 k = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 depths = [int(x) for x in sys.argv[2:]] or [2, 3, 4]
+import os
+STAGGER = float(os.environ.get("STAGGER_MS", "0")) * 1e-3  # host-side delay before every up-front enqueue but the first
 W, H, nf = 320, 240, 256
 dev = torch.from_numpy(synth.mixed_batch(nf, W, H, seed0=1234)).cuda()
 for depth in depths:
@@ -19,6 +21,9 @@ for depth in depths:
     def block(k, stamps=None):
         started = min(depth, k)
         for i in range(started):
+            if i and STAGGER:
+                t_s = time.perf_counter()
+                while time.perf_counter() - t_s < STAGGER: pass
             ctxs[i].detect_enqueue(0)
         if stamps is not None: stamps.append(time.perf_counter())
         for i in range(k):

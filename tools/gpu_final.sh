@@ -10,6 +10,8 @@ echo "== pytest gpu"; timeout 1500 python -m pytest tests -m gpu -q --no-header 
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
 t0=$(date +%s)
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench default exit $? ($(( $(date +%s) - t0 )) s)"; cut -c1-300 $OUT/bench_default.json
+# the command the driver runs at round end (BENCH_rNN.json: 20 timed steps = a 5 ms block for the primary workload)
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "bench driver-style exit $?"; cut -c1-300 $OUT/bench_driver.json
 timeout 600 python bench.py --workload c5 --feeds 8 > $OUT/bench_c5.json 2> $OUT/bench_c5.err; echo "bench c5 exit $?"; cut -c1-200 $OUT/bench_c5.json
 if [ "${RUN_PROF:-1}" = 1 ]; then
 cd /tmp

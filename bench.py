@@ -579,14 +579,12 @@ def stream_bench(env, a, feeds=1, steps=300, warm_cycles=1, cpu_seconds=0.0):
     nuniq = 30
     fbytes = W * H * 4
     # time step k of feed f = a face drifting 3 px / frame over a flat background, feed f running 7 f frames ahead
-    uniq = np.empty((nuniq, H, W, 4), dtype=np.uint8)
-    for k in range(nuniq):
-        uniq[k] = synth.face_frame(W, H, [(700 + 3 * k + 40 * rank, 300 + k, 360)])
+    uniq = synth.stream_feed_frames(nuniq, W, H, rank)
     host = torch.empty((nuniq, K, H, W, 4), dtype=torch.uint8).pin_memory()
     hv = host.numpy()
     for k in range(nuniq):
         for f in range(K):
-            hv[k, f] = uniq[(k + 7 * f) % nuniq]
+            hv[k, f] = uniq[synth.stream_frame_index(k, f, nuniq)]
     dev = host.cuda()  # the same steps resident in HBM (nuniq x K x 8.3 MB)
     ctx = Context(device=local)
     ctx.set_geometry(W, H, K)

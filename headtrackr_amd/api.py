@@ -22,10 +22,13 @@ class Context:
     """One ht_ctx: one GPU, one cascade, one stream."""
 
     def __init__(self, cascade: Cascade | None = None, device: int = 0, interval: int = 5, stream: int | None = None,
-                 hit_capacity: int = 0, queue_capacity: int = 0):
+                 hit_capacity: int = 0, queue_capacity: int = 0, options: str | dict | None = None):
+        """options: ht_config.options — "key=value,..." or a dict (schedule selectors for tests / A-B runs; results never change)"""
         self._lib = native.lib()
         self.cascade = cascade or load_cascade()
-        cfg = native.Config(C.sizeof(native.Config), device, interval, hit_capacity, stream, queue_capacity, 0)
+        if isinstance(options, dict):
+            options = ",".join(f"{k}={int(v)}" for k, v in options.items())
+        cfg = native.Config(C.sizeof(native.Config), device, interval, hit_capacity, stream, queue_capacity, 0, options.encode() if options else None)
         h = C.c_void_p()
         blob = self.cascade.blob
         st = self._lib.ht_create(C.byref(cfg), blob, len(blob), C.byref(h))

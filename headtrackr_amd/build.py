@@ -24,9 +24,8 @@ HIP_FLAGS = [
     "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
     "-I", os.path.join(ROOT, "include"), "-I", CSRC,
 ]
-for _knob in ("HT_TILE_NT", "HT_TILE_TYH", "HT_TILE_WPS", "HT_TILE_WAVEQ", "HT_TILE_PAIR", "HT_TILE_PAIRPK", "HT_TILE_PRIO", "HT_RS_WPS", "HT_RS_ROWPF", "HT_RS_PACKED", "HT_RS_PITCH", "HT_RS_EXPERIMENT", "HT_RS_PRIO", "HT_DEEPL_WAVES", "HT_TAIL_NT", "HT_TAIL_U"):  # measurement knobs: scan-tile workgroup size / tile height / waves per SIMD
-    if os.environ.get(_knob):
-        HIP_FLAGS.append(f"-D{_knob}=" + os.environ[_knob])
+# The product build takes NO knobs from the environment: variants (instrumented / experimental kernels) are built by
+# tools/build_alt.py with explicit -D arguments into alt/, never into the product library.
 
 
 # per-source flags.  ht_camshift.hip: MachineLICM hoists the constant tables of the once-per-call epilogue (atan2 / sqrt polynomials, 40+

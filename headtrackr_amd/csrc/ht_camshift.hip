@@ -390,7 +390,7 @@ __device__ __forceinline__ void meanshift_body(int W, int H, const int *s_sw, Ht
     Mom m = {0, 0, 0, 0, 0, 0};
     int wadx = 0, wady = 0, wadw = 0, wadh = 0;
     unsigned long long visited = 0;  // window pixels read by the moment passes (B_track = 4*W*H + 4*sum(window))
-    for (int it = 0; it < max_it; it++) {  // camshift.js:284-306; max_it = 10 (HT_DEBUG_CS_ITERS: measurement knob, wrong results)
+    for (int it = 0; it < max_it; it++) {  // camshift.js:284-306; max_it = 10 (option cs_iters: measurement knob, wrong results)
         wadx = max(swx, 0);
         wady = max(swy, 0);
         wadw = min(wadx + sww, W);
@@ -1163,7 +1163,7 @@ Rccl &rccl() {
 
 extern "C" ht_status ht_allgather_records(ht_ctx *const *ctxs, int32_t nranks, void *const *records_dev, size_t bytes_per_rank) {
     if (!ctxs || !records_dev || nranks <= 0 || bytes_per_rank == 0) return HT_ERR_INVALID;
-    if (nranks == 1 && !getenv("HT_DEBUG_FORCE_RCCL")) return HT_OK;  // (the knob runs RCCL with one rank: dlopen + ncclCommInitAll + ncclAllGather on a 1-GPU box)
+    if (nranks == 1 && ctxs[0] && !ctxs[0]->force_rccl) return HT_OK;  // (option force_rccl runs RCCL with one rank: dlopen + ncclCommInitAll + ncclAllGather on a 1-GPU box)
     std::vector<int> devs(nranks);
     for (int i = 0; i < nranks; i++) {
         if (!ctxs[i] || !records_dev[i]) return HT_ERR_INVALID;

@@ -7,6 +7,7 @@
 //   grouping            ccv.js:34-107 (array_group), 249-332 (averaging, nested-rect filter)
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -180,8 +181,71 @@ static ht_status upload_cascade(ht_ctx *c) {
     return ht_scan_tile_tables(c);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ht_config.options: "key=value,key=value".  Every key selects among schedules with identical results; the three that do not
+// (results incomplete by design: timing experiments) exist only with -DHT_DEBUG_KNOBS.
+static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) {
+    size_t pos = 0;
+    while (pos < opts.size()) {
+        size_t end = opts.find(',', pos);
+        if (end == std::string::npos) end = opts.size();
+        std::string kv = opts.substr(pos, end - pos);
+        pos = end + 1;
+        while (!kv.empty() && (kv.front() == ' ')) kv.erase(kv.begin());
+        while (!kv.empty() && (kv.back() == ' ')) kv.pop_back();
+        if (kv.empty()) continue;
+        const size_t eq = kv.find('=');
+        const std::string key = kv.substr(0, eq), val = eq == std::string::npos ? "1" : kv.substr(eq + 1);
+        char *endp = nullptr;
+        const long long v = std::strtoll(val.c_str(), &endp, 10);
+        if (val.empty() || (endp && *endp)) {
+            why = "option '" + key + "': value is not an integer";
+            return false;
+        }
+        const int iv = (int)std::max<long long>(std::min<long long>(v, 1ll << 30), -(1ll << 30));
+        if (key == "rs_rpt") { if (iv >= 1 && iv <= HT_RS_MAX_PASSES) c->rs_rpt = iv; }
+        else if (key == "rs_tailtable") c->tail_table = iv != 0, c->tail_table_forced = true;
+        else if (key == "rs_tailcap") c->rs_tailcap = (uint64_t)std::max<long long>(v, 0);
+        else if (key == "rs_notail") c->rs_notail = iv != 0;
+        else if (key == "rs_nofast") c->rs_nofast = iv != 0;
+        else if (key == "rs_nosort") c->rs_nosort = iv != 0;
+        else if (key == "rs_gennames") c->rs_gennames = iv != 0;
+        else if (key == "rs_minwg") c->rs_min_wgs = std::max(1, iv);
+        else if (key == "rs_k") c->dbg_rs_k = iv;
+        else if (key == "rs_group") { if (iv >= 1 && iv <= 64) c->rs_group = iv; }
+        else if (key == "early_scan") c->early_scan = iv != 0;
+        else if (key == "force_exact") c->dbg_force_exact = iv;
+        else if (key == "deep_bias") c->deep_bias = (uint32_t)std::max(0, iv);
+        else if (key == "deep_v") c->dbg_deep_v = iv;
+        else if (key == "deep_grid") c->deep_grid = std::max(1, iv);
+        else if (key == "split") c->opt_split = std::max(1, iv);
+        else if (key == "cs_fused_min") c->cs_fused_min_streams = std::max(1, iv);
+        else if (key == "cs_keep_hist") c->cs_keep_hist = iv != 0;
+        else if (key == "cs_seq_fused") c->cs_seq_fused = iv != 0;
+        else if (key == "cs_cluster") c->cs_cluster = iv != 0;
+        else if (key == "cs_cluster_min_px") c->cs_cluster_min_px = (uint32_t)std::max(0, iv);
+        else if (key == "cs_region") c->cs_region_cap = std::min(40960, std::max(0, iv));
+        else if (key == "cs_barrier_budget") c->cs_barrier_budget = std::max(1ll, v);
+        else if (key == "graph_max_frames") c->graph_max_frames = std::max(0, iv);
+        else if (key == "host_threads") c->host_threads = std::min(64, std::max(0, iv));
+        else if (key == "force_rccl") c->force_rccl = iv != 0;
+#ifdef HT_DEBUG_KNOBS
+        else if (key == "stop_stage") c->dbg_stop_stage = iv;                        // the tile kernel stops before this stage
+        else if (key == "cs_iters") c->dbg_cs_iters = std::min(10, std::max(0, iv));   // mean-shift iterations (camshift.js:284 has 10)
+        else if (key == "rs_maxgen") c->rs_maxgen = iv;                                // pyramid generations built
+#endif
+        else {
+            why = "unknown option '" + key + "'";
+            return false;
+        }
+    }
+    return true;
+}
+
 extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, size_t cascade_len, ht_ctx **out) {
-    if (!cfg || !out || cfg->struct_size != sizeof(ht_config)) return ht_fail(nullptr, HT_ERR_INVALID, "ht_create: bad config");
+    // ABI 1 callers pass the struct without its last member (options)
+    if (!cfg || !out || (cfg->struct_size != sizeof(ht_config) && cfg->struct_size != offsetof(ht_config, options)))
+        return ht_fail(nullptr, HT_ERR_INVALID, "ht_create: bad config");
     *out = nullptr;
     if (cfg->interval < 1 || cfg->interval > 12) return ht_fail(nullptr, HT_ERR_INVALID, "ht_create: interval must be 1..12");
     int ndev = 0;
@@ -224,12 +288,18 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         }
         c->own_stream = true;
     }
-    if (const char *e = getenv("HT_DEBUG_RS_RPT")) {  // measurement knob
-        const int v = atoi(e);
-        if (v >= 1 && v <= HT_RS_MAX_PASSES) c->rs_rpt = v;
+    // per-context options (schedule selectors for tests / A-B runs): from the config string only — this library reads no environment
+    {
+        std::string opts = (cfg->struct_size >= offsetof(ht_config, options) + sizeof(const char *) && cfg->options) ? cfg->options : "";
+#ifdef HT_DEBUG_KNOBS  // instrumented builds (tools/build_alt.py) may also be steered from the shell
+        if (const char *e = std::getenv("HT_OPTIONS")) opts += std::string(opts.empty() ? "" : ",") + e;
+#endif
+        std::string why;
+        if (!apply_options(c, opts, why)) {
+            c->err = "ht_create: " + why;
+            return bail(HT_ERR_INVALID);
+        }
     }
-    if (const char *e = getenv("HT_DEBUG_RS_TAILTABLE")) c->tail_table = atoi(e) != 0;
-    if (const char *e = getenv("HT_DEBUG_EARLY_SCAN")) c->early_scan = atoi(e) != 0;
     if (c->early_scan) {
         if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_early_ready, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&c->ev_early_done, hipEventDisableTiming) != hipSuccess) {
@@ -237,32 +307,11 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
             return bail(HT_ERR_HIP);
         }
     }
-    if (const char *e = getenv("HT_DEBUG_RS_MINWG")) c->rs_min_wgs = std::max(1, atoi(e));  // measurement knob
-    if (const char *e = getenv("HT_DEBUG_RS_K")) c->dbg_rs_k = atoi(e);
-    if (const char *e = getenv("HT_DEBUG_RS_GROUP")) {  // measurement knob
-        const int v = atoi(e);
-        if (v >= 1 && v <= 64) c->rs_group = v;
-    }
-    // measurement / test knobs (never set in production), read once here — not on the launch path
-    if (const char *e = getenv("HT_DEBUG_STOP_STAGE")) c->dbg_stop_stage = atoi(e);
-    if (const char *e = getenv("HT_DEBUG_FORCE_EXACT")) c->dbg_force_exact = atoi(e);
-    if (const char *e = getenv("HT_DEBUG_DEEP_BIAS")) c->deep_bias = (uint32_t)atoi(e);
-    if (const char *e = getenv("HT_DEBUG_DEEP_V")) c->dbg_deep_v = atoi(e);
-    if (const char *e = getenv("HT_DEBUG_DEEP_GRID")) c->deep_grid = std::max(1, atoi(e));
-    if (const char *e = getenv("HT_DEBUG_CS_FUSED_MIN")) c->cs_fused_min_streams = std::max(1, atoi(e));
-    if (getenv("HT_DEBUG_CS_KEEP_HIST")) c->cs_keep_hist = true;
-    if (const char *e = getenv("HT_DEBUG_CS_SEQ_FUSED")) c->cs_seq_fused = atoi(e) != 0;
-    if (const char *e = getenv("HT_DEBUG_CS_CLUSTER")) c->cs_cluster = atoi(e) != 0;
-    if (const char *e = getenv("HT_DEBUG_CS_CLUSTER_MINPX")) c->cs_cluster_min_px = (uint32_t)std::max(0, atoi(e));
-    if (const char *e = getenv("HT_DEBUG_CS_REGION")) c->cs_region_cap = std::min(40960, std::max(0, atoi(e)));
-    if (const char *e = getenv("HT_DEBUG_CS_ITERS")) c->dbg_cs_iters = std::min(10, std::max(0, atoi(e)));
-    if (const char *e = getenv("HT_DEBUG_GRAPH_MAXFRAMES")) c->graph_max_frames = std::max(0, atoi(e));  // 0: never replay graphs (A/B)
-    if (const char *e = getenv("HT_DEBUG_CS_BARRIER_BUDGET")) c->cs_barrier_budget = std::max(1ll, atoll(e));  // test knob: forces barrier time-outs
     c->builtin_cascade = ht_scan_is_builtin_cascade((const uint8_t *)cascade_blob, cascade_len) && c->interval >= 1;
     // stages [0, split) always run in the tile kernel: the generated straight-line stages for the built-in cascade
     c->split_stage = std::min<uint32_t>(c->builtin_cascade ? 8u : 4u, c->nstages);
-    if (const char *e = getenv("HT_DEBUG_SPLIT"))  // measurement knob: hand-off stage (<= 8 for the generated stage code)
-        c->split_stage = std::min<uint32_t>((uint32_t)std::max(1, atoi(e)), std::min<uint32_t>(c->builtin_cascade ? 8u : c->nstages, c->nstages));
+    if (c->opt_split > 0)  // option split: hand-off stage (<= 8 for the generated stage code)
+        c->split_stage = std::min<uint32_t>((uint32_t)c->opt_split, std::min<uint32_t>(c->builtin_cascade ? 8u : c->nstages, c->nstages));
     if ((st = upload_cascade(c)) != HT_OK) return bail(st);
     if ((st = ht_scan_pack_deep(c)) != HT_OK) return bail(st);
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), sizeof(HtCounters) + (size_t)HT_PINNED_HITS * sizeof(ht_hit), hipHostMallocDefault) != hipSuccess ||
@@ -478,9 +527,9 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
                 for (int x = 0; x < nbx; x++) {
                     HtResampleJob t = j;
                     t.bx = (uint16_t)x, t.pass0 = (uint16_t)pass0, t.np = (uint16_t)np;
-                    // bit 0: exact 2:1 in both directions (2x2 box mean, see the BOX rows of k_resample); HT_DEBUG_RS_NOFAST=1 keeps
+                    // bit 0: exact 2:1 in both directions (2x2 box mean, see the BOX rows of k_resample); option rs_nofast keeps
                     // every pixel on the declared binary64 sequence (A/B and cross-check)
-                    t.pad = getenv("HT_DEBUG_RS_NOFAST") ? 2 : (uint16_t)((j.dw > 0 && j.sw == 2 * j.dw && j.sh == 2 * j.dh) ? 1 : 0);
+                    t.pad = c->rs_nofast ? 2 : (uint16_t)((j.dw > 0 && j.sw == 2 * j.dw && j.sh == 2 * j.dh) ? 1 : 0);
                     const int X0 = 64 * x, Y0 = 16 * pass0, ncols = std::min(64, j.dw - X0), nrows = std::min(16 * np, j.dh - Y0);
                     if (ncols > 0 && nrows > 0) {  // the source extent k_resample stages into LDS (same expressions as in the kernel)
                         t.ex_xa = ht_host_tap(X0, j.rx, j.sw, j.sx).a & ~15;
@@ -496,7 +545,7 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
         // launch order = source order: tiles of different drawImage calls that read the same rows of the same source
         // plane (levels 1..6 all read level 0; the four variants of a level read the same parent) run back to back on
         // an XCD, so the source band is fetched from HBM once and then served by that XCD's L2
-        if (!getenv("HT_DEBUG_RS_NOSORT"))
+        if (!c->rs_nosort)
             std::stable_sort(tiles.begin(), tiles.end(), [](const HtResampleJob &a, const HtResampleJob &b) {
                 if (a.src_off != b.src_off) return a.src_off < b.src_off;
                 const int ya = (int)(16.0 * a.pass0 * a.ry), yb = (int)(16.0 * b.pass0 * b.ry);
@@ -518,16 +567,16 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
     // tail plan: from the first generation g0 on which every generation has <= HT_TAIL_MAX_JOBS jobs and all of them
     // together <= tail_cap destination pixels per frame, one workgroup per frame does the rest of the pyramid in one launch
     // (k_resample_tail) instead of one nearly empty launch per generation.
-    const uint64_t tail_cap = getenv("HT_DEBUG_RS_TAILCAP") ? (uint64_t)atoll(getenv("HT_DEBUG_RS_TAILCAP")) : 32768u;
+    const uint64_t tail_cap = c->rs_tailcap;
     // which tail kernel: measured (3 batches in flight), the table-driven binary32 tail (68 VGPRs, 35 KB LDS) is worth +4-5 % at
     // 128 x 720p but costs 3 % at 256 x 320x240, where its grid puts a 1024-thread workgroup on EVERY CU and its footprint keeps
     // the other batches' kernels from sharing them; the round-1 binary64 tail (41 VGPRs) is kept for batches that cover the chip.
     // Larger caps (generation 3 of C2 = 54 k pixels in the tail) lose with either kernel.
-    if (!getenv("HT_DEBUG_RS_TAILTABLE")) c->tail_table = max_batch <= 128;
+    if (!c->tail_table_forced) c->tail_table = max_batch <= 128;
     c->tail_first_gen = 0;
     if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
     if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;
-    if (!getenv("HT_DEBUG_RS_NOTAIL")) {
+    if (!c->rs_notail) {
         int g0 = ngen;
         uint64_t px = 0;
         for (int g = ngen - 1; g >= 1; g--) {
@@ -563,7 +612,7 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
                 std::vector<HtTap> taps;
                 std::vector<HtTapFast> fast;
                 std::vector<HtTailTapRef> refs;
-                const bool nofast = getenv("HT_DEBUG_RS_NOFAST") != nullptr;
+                const bool nofast = c->rs_nofast;
                 size_t jidx = 0;
                 for (auto &j : tj) {
                     for (int g = 0; g <= T.ngen; g++)
@@ -814,6 +863,7 @@ static ht_status wb_scratch(ht_ctx *c) {
     const size_t region = sizeof(unsigned long long) * 4 * (size_t)std::max(c->max_batch, 1), need = 2 * region;
     if (c->d_scratch_bytes < need) {
         HT_HIP(c, hipStreamSynchronize(c->stream));
+        destroy_graphs(c);  // captured detect sequences bake the d_scratch pointer into their gray / whitebalance nodes
         if (c->d_scratch) (void)hipFree(c->d_scratch);
         c->d_scratch = nullptr;
         c->d_scratch_bytes = 0;

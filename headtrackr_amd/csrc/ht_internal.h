@@ -108,7 +108,7 @@ struct HtTapFast {
 };
 struct HtTailTapRef {
     uint32_t col, row;  // first column / row tap of the job in both tables
-    uint32_t mode;      // bit 0: exact 2:1 in both directions (integer 2x2 box mean), bit 1: binary64 everywhere (HT_DEBUG_RS_NOFAST)
+    uint32_t mode;      // bit 0: exact 2:1 in both directions (integer 2x2 box mean), bit 1: binary64 everywhere (option rs_nofast)
     uint32_t pad;
 };
 
@@ -195,6 +195,9 @@ struct alignas(16) HtCsState {
 
 // A captured detect sequence (memsets + gray + pyramid generations + scan kernels: ~10 dependent launches) replayed with one
 // hipGraphLaunch.  Keyed by everything the kernels' arguments depend on besides the geometry (which owns the cache).
+// INVARIANT: a captured graph bakes in d_arena, d_counters, d_hits, d_queue, d_stats, the tile / job tables and d_scratch.  The first
+// four live as long as the context; the geometry's allocations are only freed by free_geometry(), d_scratch only by wb_scratch() — both
+// call destroy_graphs() first.  Anything else that reallocates a buffer a detect kernel reads must do the same.
 struct HtDetectGraph {
     const uint8_t *frames = nullptr;
     size_t frame_stride = 0;
@@ -217,7 +220,7 @@ struct ht_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // early scan (opt-in, HT_DEBUG_EARLY_SCAN=1): the scales whose three planes exist after pyramid generation `early_gen` are
+    // early scan (opt-in, option early_scan=1): the scales whose three planes exist after pyramid generation `early_gen` are
     // scanned on a second stream while the main stream builds the remaining (small, latency-bound) generations.  Measured with
     // 3 batches in flight: +2.5 % at 128 x 720p, -12 % at 256 x 320x240 (the other batches already fill those gaps; the extra
     // concurrency only adds contention), so it is off by default; it shortens the latency of a single batch in flight.
@@ -243,9 +246,10 @@ struct ht_ctx {
     bool builtin_cascade = false;  // blob == the cascade ht_cascade_gen.inc was generated from
     uint32_t deep_bias = 1;        // tile kernel hands survivors to the deep kernel when n*bias*ceil(count/64) <= count
                                    // (measured on C2/C4: split 8 + bias 0..1 is the optimum, profiles/r01_sweeps.txt)
-    int dbg_stop_stage = -1, dbg_force_exact = 0, dbg_deep_v = 4, deep_grid = 512;  // HT_DEBUG_* knobs, read once in ht_create
+    int dbg_stop_stage = -1, dbg_force_exact = 0, dbg_deep_v = 4, deep_grid = 512;  // ht_config.options, parsed once in ht_create
     HtDevStage *d_stages = nullptr;
     uint32_t split_stage = 4;  // stages [0, split) in the tile kernel, [split, nstages) in the deep kernel
+    int opt_split = 0;         // option split (0 = default)
 
     // geometry
     int W = 0, H = 0, max_batch = 0, nlevels = 0, upto = 0;
@@ -270,10 +274,16 @@ struct ht_ctx {
     HtTailTapRef *d_tail_tapref = nullptr;   // per tail job: where its taps start
     HtTailGens h_tail;                       // per generation: job range and group count (kernel argument)
     bool deep_attr_set = false;              // k_scan_deep_lds: > 64 KB dynamic LDS enabled on this context's device
-    bool tail_table = true;  // k_resample_tail with host tap tables (false: the round-1 binary64 tail, HT_DEBUG_RS_TAILTABLE=0)
-    int rs_min_wgs = 2048;  // ... but never fewer workgroups per launch than this (HT_DEBUG_RS_MINWG)
-    int dbg_rs_k = 0;  // HT_DEBUG_RS_K: frames per k_resample workgroup, forced (any value)
-    int rs_group = 8;  // k_resample: frames per workgroup at most (HT_DEBUG_RS_GROUP)
+    bool tail_table = true;  // k_resample_tail with host tap tables (false: the round-1 binary64 tail; option rs_tailtable)
+    bool tail_table_forced = false;  // option rs_tailtable given: ht_set_geometry keeps it instead of choosing by batch size
+    bool rs_nofast = false, rs_nosort = false, rs_notail = false, rs_gennames = false;  // options of the same names (A/B, cross-checks)
+    uint64_t rs_tailcap = 32768;     // destination pixels per frame the tail kernel takes at most (option rs_tailcap)
+    int rs_maxgen = 1 << 30;         // HT_DEBUG_KNOBS builds only (results stale): pyramid generations built
+    bool force_rccl = false;         // option force_rccl: ht_allgather_* runs RCCL even with one rank
+    int host_threads = -1;           // option host_threads: workers of the host post-processing (-1 = auto, 0 = none)
+    int rs_min_wgs = 2048;  // ... but never fewer workgroups per launch than this (option rs_minwg)
+    int dbg_rs_k = 0;  // option rs_k: frames per k_resample workgroup, forced (any value)
+    int rs_group = 8;  // k_resample: frames per workgroup at most (option rs_group)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
 
     // frames
@@ -288,7 +298,7 @@ struct ht_ctx {
     size_t frame_stride = 0;
     int nframes = 0;
     // small batches (a live feed = 1 frame) are launch-bound: ~10 dependent launches cost more than their kernels.  Their sequence is
-    // captured into a hipGraph per (frames pointer, count, flags) and replayed.  0 disables (HT_DEBUG_GRAPH_MAXFRAMES)
+    // captured into a hipGraph per (frames pointer, count, flags) and replayed.  0 disables (option graph_max_frames)
     int graph_max_frames = 16;
     std::vector<HtDetectGraph> graphs;
     uint64_t graph_launches = 0;  // measurement: enqueues served by a graph replay
@@ -331,8 +341,8 @@ struct ht_ctx {
     ht_cs_trackobj *d_cs_out = nullptr;
     double *d_cs_lut = nullptr, *d_cs_parts = nullptr;  // cluster mean-shift: per-stream weight LUT, partial-sum exchange slots
     unsigned long long *d_cs_ctr = nullptr;             // ... and arrival counters (zeroed before every launch)
-    bool cs_cluster = true;                              // HT_DEBUG_CS_CLUSTER=0 disables the cluster path
-    uint32_t cs_cluster_min_px = 400000;                 // frames at least this large take it (HT_DEBUG_CS_CLUSTER_MINPX)
+    bool cs_cluster = true;                              // option cs_cluster=0 disables the cluster path
+    uint32_t cs_cluster_min_px = 400000;                 // frames at least this large take it (option cs_cluster_min_px)
     ht_cs_trackobj *d_cs_seq_out = nullptr;  // ht_camshift_track_sequence: [calls][streams] results, one D2H at the end
     size_t cs_seq_cap = 0;
     // the sequence enqueued with out == NULL that ht_camshift_sequence_collect may fetch (n == 0: none pending)
@@ -340,15 +350,15 @@ struct ht_ctx {
     int cs_track_pending_n = 0;        // streams of the ht_camshift_track_batch enqueued with out == NULL (ht_camshift_track_collect)
     uint32_t *d_cs_err = nullptr;      // device word: a cluster barrier ran out of its cycle budget (k_cs_meanshift_cluster)
     uint32_t *h_cs_err = nullptr;      // pinned copy, fetched with every result read-back
-    long long cs_barrier_budget = 1ll << 28;  // shader-clock cycles a workgroup waits at one cluster barrier (HT_DEBUG_CS_BARRIER_BUDGET)
+    long long cs_barrier_budget = 1ll << 28;  // shader-clock cycles a workgroup waits at one cluster barrier (option cs_barrier_budget)
     int num_cus = 256;                 // hipDeviceProp_t::multiProcessorCount: sizes the cluster of k_cs_meanshift_cluster
-    int cs_fused_min_streams = 192;  // >= this many streams per call: k_cs_track_fused (HT_DEBUG_CS_FUSED_MIN)
+    int cs_fused_min_streams = 192;  // >= this many streams per call: k_cs_track_fused (option cs_fused_min)
     bool cs_seq_attr_set = false;
-    bool cs_seq_fused = true;      // HT_DEBUG_CS_SEQ_FUSED=0: ht_camshift_track_sequence launches one kernel per call (A/B)
-    int dbg_cs_iters = 10;            // HT_DEBUG_CS_ITERS: mean-shift iterations at most (camshift.js:284 has 10; anything else = wrong results)
+    bool cs_seq_fused = true;      // option cs_seq_fused=0: ht_camshift_track_sequence launches one kernel per call (A/B)
+    int dbg_cs_iters = 10;            // option cs_iters: mean-shift iterations at most (camshift.js:284 has 10; anything else = wrong results)
     bool cs_keep_hist = false;
     bool cs_attr_set = false;         // > 64 KB dynamic LDS enabled for the camshift kernels on this context's device
-    int cs_region_cap = 40960;        // pixels of the LDS-cached search region (HT_DEBUG_CS_REGION=0 disables it)        // HT_DEBUG_CS_KEEP_HIST: the fused kernel also writes its histogram for ht_camshift_debug_hist
+    int cs_region_cap = 40960;        // pixels of the LDS-cached search region (option cs_region=0 disables it)        // option cs_keep_hist: the fused kernel also writes its histogram for ht_camshift_debug_hist
     int cs_last_first = 0, cs_last_n = 0, cs_last_chunks = 0;  // layout of d_cs_hist after the last track call (debug read-back)
 
     std::vector<std::pair<void *, size_t>> user_allocs;  // ht_device_alloc buffers still alive (pointer, bytes): freed by ht_destroy at the latest

@@ -177,6 +177,17 @@ napi_value CreateContext(napi_env env, napi_callback_info info) {
         NAPI_OK(napi_get_named_property(env, argv[0], "queueCapacity", &v));
         if (get_i32(env, v, &i)) cfg.queue_capacity = (uint32_t)i;
     }
+    std::string options;  // ht_config.options: "key=value,..." schedule selectors (tests, A/B runs)
+    if (napi_has_named_property(env, argv[0], "options", &has) == napi_ok && has) {
+        NAPI_OK(napi_get_named_property(env, argv[0], "options", &v));
+        size_t len = 0;
+        if (napi_get_value_string_utf8(env, v, nullptr, 0, &len) == napi_ok) {
+            options.resize(len + 1);
+            NAPI_OK(napi_get_value_string_utf8(env, v, &options[0], len + 1, &len));
+            options.resize(len);
+            cfg.options = options.c_str();
+        }
+    }
     NAPI_OK(napi_get_named_property(env, argv[0], "cascade", &v));
     if (!get_bytes(env, v, &blob, &blob_len)) {
         napi_throw_type_error(env, nullptr, "createContext: `cascade` must be a Buffer/Uint8Array holding an HTCB blob");

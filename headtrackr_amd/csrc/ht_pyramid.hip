@@ -234,6 +234,9 @@ constexpr float RS_EPS = 1.0f / 8192.0f;
 #ifndef HT_RS_PACKED
 #define HT_RS_PACKED 1  // 1 = top / bot of a pixel as one packed pair (v_pk_add_f32 + v_pk_fma_f32: 4.5 cycles for two, tools/micro/valu_rate_bench.hip)
 #endif
+#if defined(HT_RS_EXPERIMENT) && HT_RS_EXPERIMENT && !defined(HT_DEBUG_KNOBS)
+#error "HT_RS_EXPERIMENT builds compute wrong results by design: only together with -DHT_DEBUG_KNOBS (tools/build_alt.py)"
+#endif
 #ifndef HT_RS_EXPERIMENT
 #define HT_RS_EXPERIMENT 0  // timing experiments only (results are wrong): 1 = no pixel arithmetic, 2 = no source loads after the first frame, 3 = no stores
 #endif
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
         uint32_t one = 1u;
         asm volatile("" : "+s"(one));
         const uint32_t mode = J.pad;  // bit 0: 2x2 box mean (both ratios exactly 2), bit 1: binary64 everywhere (set by the host)
-        // binary64 everywhere (HT_DEBUG_RS_NOFAST) = every pixel takes the fallback: a threshold no distance can stay under
+        // binary64 everywhere (option rs_nofast) = every pixel takes the fallback: a threshold no distance can stay under
         const float thr = (mode & 2u) ? -1.0f : 0.5f - RS_EPS;
         const int dh = J.dh, ch = J.ch, dst_stride = J.dst_stride;
         const uint32_t doff = J.dst_off + (uint32_t)(yt * dst_stride + x0);
@@ -754,7 +757,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_resample_tail(const HtResampleJob *
                     }
                     const uint32_t keep = npx[u] >= 4 ? 0xffffffffu : ((1u << (8 * npx[u])) - 1u);
                     if (mode[u] & 1u) o = obox, need = 0;
-                    if (mode[u] & 2u) need = 0xfu;  // HT_DEBUG_RS_NOFAST: binary64 everywhere
+                    if (mode[u] & 2u) need = 0xfu;  // option rs_nofast: binary64 everywhere
                     need &= (1u << npx[u]) - 1u;
                     o &= keep;
                     if (need) {
@@ -774,7 +777,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_resample_tail(const HtResampleJob *
     }
 }
 
-// the round-1 tail kernel: taps re-derived per group in registers, binary64 lerps (kept for A/B: HT_DEBUG_RS_TAILTABLE=0)
+// the round-1 tail kernel: taps re-derived per group in registers, binary64 lerps (kept for A/B: option rs_tailtable=0)
 constexpr int TAILF_NT = 1024;
 __global__ __launch_bounds__(TAILF_NT) void k_resample_tail_f64(const HtResampleJob *__restrict__ jobs, const uint32_t *__restrict__ prefix,
                                                           const HtTailGens G, uint8_t *__restrict__ arena, uint64_t arena_stride,
@@ -886,19 +889,19 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         HT_HIP(c, hipGetLastError());
     }
     const size_t regular_end = c->tail_first_gen > 0 ? (size_t)c->tail_first_gen : c->h_gens.size();
-    static const int dbg_maxgen = getenv("HT_DEBUG_RS_MAXGEN") ? atoi(getenv("HT_DEBUG_RS_MAXGEN")) : 1 << 30;  // measurement knob (results stale): what do the later generations cost the wall clock?
+    const int dbg_maxgen = c->rs_maxgen;  // 1 << 30 unless a -DHT_DEBUG_KNOBS build was told otherwise (results stale: what do the later generations cost the wall clock?)
     for (size_t g = 1; g < regular_end; g++) {
         if (c->gen_blocks[g] == 0 || (int)g > dbg_maxgen) continue;
         char gname[24];
         std::snprintf(gname, sizeof(gname), "resample_g%d", (int)g);
-        HtProfScope ps(c, getenv("HT_DEBUG_RS_GENNAMES") ? gname : "resample");  // measurement knob: device time per pyramid generation
+        HtProfScope ps(c, c->rs_gennames ? gname : "resample");  // option rs_gennames: device time per pyramid generation
         // frames per workgroup: as many as keep >= ~4 workgroups per CU slot in the launch, at most rs_group; groups never
         // straddle the 8 XCD shares of the batch when the batch is a multiple of 8 * K
         uint32_t K = 1;
         while (K * 2 <= (uint32_t)c->rs_group && (uint64_t)c->gen_blocks[g] * ((uint32_t)c->nframes / (K * 2)) >= (uint64_t)c->rs_min_wgs &&
                (uint32_t)c->nframes % (K * 2 * 8) == 0)
             K *= 2;
-        if (c->dbg_rs_k > 0) K = (uint32_t)std::min(c->dbg_rs_k, std::max(1, c->nframes));  // HT_DEBUG_RS_K: measurement knob
+        if (c->dbg_rs_k > 0) K = (uint32_t)std::min(c->dbg_rs_k, std::max(1, c->nframes));  // option rs_k: measurement knob
         const uint32_t ngroups = ((uint32_t)c->nframes + K - 1) / K;
         const dim3 rgrid((c->gen_blocks[g] * ngroups + 7u) & ~7u);
         hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,
@@ -910,7 +913,7 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         }
     }
     if (c->tail_first_gen > 0 && c->tail_first_gen <= dbg_maxgen) {
-        HtProfScope ps(c, getenv("HT_DEBUG_RS_GENNAMES") ? "resample_tail" : "resample");
+        HtProfScope ps(c, c->rs_gennames ? "resample_tail" : "resample");
         if (c->tail_table)
             hipLaunchKernelGGL(k_resample_tail, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
                                c->d_tail_tapref, c->d_tail_taps_fast, c->d_tail_taps, c->h_tail, c->d_arena, c->arena_stride, (uint32_t)c->nframes);

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     }
     // ---- shared-queue cascade, table-driven stages: other cascades from stage 0, the built-in one past its generated stages
     for (int s = s_first; s < nstages; s++) {
-        if (s == stop_stage) return;  // measurement knob (HT_DEBUG_STOP_STAGE): results are incomplete when set
+        if (s == stop_stage) return;  // measurement knob (option stop_stage): results are incomplete when set
         const HtDevStage st = stages[s];
         // hand-off rule: from stage `split` on, survivors leave for k_scan_deep (one wavefront per window, features
         // across lanes) as soon as that is cheaper than keeping them on a few lanes of this workgroup

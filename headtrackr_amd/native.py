@@ -34,6 +34,7 @@ class Config(C.Structure):
         ("stream", C.c_void_p),
         ("queue_capacity", C.c_uint32),
         ("flags", C.c_uint32),
+        ("options", C.c_char_p),  # "key=value,...": per-context schedule selectors (include/headtrackr_hip.h); None = defaults
     ]
 
 

@@ -213,3 +213,17 @@ def make(gen: dict, w: int, h: int) -> np.ndarray:
             return smooth_frame(w, h, seed)
         return face_frame(w, h, seeded_faces(w, h, seed))
     raise ValueError(f"unknown frame family {fam!r}")
+
+
+def stream_feed_frames(nuniq: int, w: int, h: int, rank: int = 0) -> np.ndarray:
+    """The C5 feeds of bench.py (BASELINE.json configs[4]): `nuniq` distinct frames of one camera — a 360-px face drifting
+    3 px right / 1 px down per frame over a flat background.  Feed f at time step k shows frame stream_frame_index(k, f, nuniq)."""
+    out = np.empty((nuniq, h, w, 4), dtype=np.uint8)
+    for k in range(nuniq):
+        out[k] = face_frame(w, h, [(700 + 3 * k + 40 * rank, 300 + k, 360)])
+    return out
+
+
+def stream_frame_index(step: int, feed: int, nuniq: int) -> int:
+    """feed f runs 7 f frames ahead of feed 0; the cycle repeats every nuniq steps"""
+    return (step % nuniq + 7 * feed) % nuniq

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define HT_ABI_VERSION 1
+#define HT_ABI_VERSION 2
 #define HT_MAX_LEVELS 96
 
 typedef int32_t ht_status;
@@ -59,6 +59,22 @@ typedef struct ht_config {
     void *stream;           /* hipStream_t to enqueue on; NULL = library-owned non-blocking stream */
     uint32_t queue_capacity;/* survivors handed from the tile kernel to the deep kernel per batch (0 = auto) */
     uint32_t flags;         /* reserved, 0 */
+    const char *options;    /* NULL, or "key=value,key=value,...": per-context schedule selectors for tests and A/B measurements
+                             * (ABI 2; a caller that passes the ABI-1 struct_size has none).  The library reads NO environment
+                             * variable: what a context computes depends on its arguments alone.  Every key below selects among
+                             * schedules that produce IDENTICAL results; an unknown key fails ht_create with HT_ERR_INVALID.
+                             *   cs_fused_min=N       streams per call from which camshift runs as one launch (default 192)
+                             *   cs_seq_fused=0|1     track sequences inside one launch (1)       cs_keep_hist=1   keep histograms for ht_camshift_debug_hist
+                             *   cs_cluster=0|1, cs_cluster_min_px=N, cs_region=N                 cluster / LDS-region paths of the few-stream schedule
+                             *   cs_barrier_budget=N  shader-clock cycles a cluster barrier may wait before the call fails with HT_ERR_STATE
+                             *   graph_max_frames=N   batches up to N frames replay a captured hipGraph (16; 0 = never)
+                             *   split=S, deep_bias=B, deep_v=2|4, deep_grid=N                    tile kernel -> deep kernel hand-off
+                             *   force_exact=1        every integer stage decision re-run on the sequential binary64 path
+                             *   early_scan=1, rs_rpt, rs_minwg, rs_k, rs_group, rs_tailtable, rs_tailcap, rs_notail, rs_nofast, rs_nosort, rs_gennames
+                             *   host_threads=N       worker threads of the host post-processing (0 = single-threaded)
+                             *   force_rccl=1         ht_allgather_* goes through RCCL even with one rank
+                             * Keys that make results incomplete by design (stop_stage, cs_iters, rs_maxgen) exist only in builds
+                             * compiled with -DHT_DEBUG_KNOBS (tools/build_alt.py); the product library rejects them. */
 } ht_config;
 
 /* One raw detection = one element of ccv.detect_objects' `seq` (ccv.js:227-234) in index form:

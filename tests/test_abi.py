@@ -33,8 +33,8 @@ def test_header_symbols_all_exported(built_lib):
 
 
 def test_abi_version_and_struct_sizes(built_lib):
-    assert built_lib.ht_abi_version() == 1
-    assert C.sizeof(native.Config) == 32
+    assert built_lib.ht_abi_version() == 2
+    assert C.sizeof(native.Config) == 40 and native.Config.options.offset == 32  # ABI 1 callers pass struct_size 32 (no options)
     assert native.HIT_DTYPE.itemsize == 24
     assert native.RECT_DTYPE.itemsize == 48
 
@@ -84,3 +84,29 @@ def test_no_kernel_spills_registers():
     assert res["k_scan_tiles<true>"]["vgpr_count"] <= 80
     assert res["k_resample<4>"]["vgpr_count"] <= 80  # 6 waves per SIMD
     assert res["k_cs_track_fused<true>"]["vgpr_count"] <= 128 and res["k_cs_track_fused<false>"]["vgpr_count"] <= 128
+
+
+
+def test_product_library_takes_no_knobs_from_the_environment(built_lib):
+    """what the library returns must depend on its arguments alone.  The product .so imports no getenv, carries
+    none of the old HT_DEBUG_* names and none of the result-changing option keys (those exist only in -DHT_DEBUG_KNOBS builds made
+    by tools/build_alt.py), and the product build passes no environment variable on to the compiler."""
+    import subprocess
+
+    from headtrackr_amd import build
+
+    so = build.LIB
+    und = subprocess.run(["nm", "-D", "--undefined-only", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in und, [l for l in und.splitlines() if "getenv" in l]
+    blob = open(so, "rb").read()
+    for needle in (b"HT_DEBUG_", b"HT_OPTIONS", b"stop_stage", b"cs_iters", b"rs_maxgen"):
+        assert needle not in blob, needle
+    src = open(build.__file__).read()
+    assert "os.environ.get(_knob)" not in src and "environ[" not in src.replace('os.environ.get("HIPCC"', "")
+    # and the options parser rejects what it does not know (needs no device: the config is validated... after the device check, so only
+    # the struct-size rule is testable here)
+    from headtrackr_amd.native import Config
+
+    cfg = Config(31, 0, 5, 0, None, 0, 0, None)
+    h = C.c_void_p()
+    assert built_lib.ht_create(C.byref(cfg), b"x", 1, C.byref(h)) == -1

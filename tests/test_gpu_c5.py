@@ -1,0 +1,132 @@
+"""Parity at the C5 shape (BASELINE.json configs[4]; /root/reference/src/main.js:168-305 -> facetrackr.js:97-108,185-217 ->
+camshift.js:198-259): 8 frame-synchronous 1920x1080 feeds as ONE batch per time step on ONE context, issued exactly the way
+bench.py's `stream_bench` issues them — bind_device to a different set of frames every step, detect by enqueue / collect-best
+(a hipGraph REPLAY from the second cycle on), camshift.initTracker on the floored best face, then enqueue-only
+ht_camshift_track_batch + ht_camshift_track_collect on 8 streams x 32 cluster workgroups — every best face and every track object
+against the oracle.  The same from the Node host: tests/js/parity_gpu.js (DeviceBatch.initTrackers / trackSequence)."""
+import math
+
+import numpy as np
+import pytest
+
+from headtrackr_amd import synth
+from headtrackr_amd.api import Context
+from oracle import ht_oracle as ho
+from test_gpu_camshift import assert_all_exact as cs_all_exact, check as cs_check
+
+pytestmark = pytest.mark.gpu
+
+W, H, NUNIQ = 1920, 1080, 30
+
+
+def c5_device_steps(uniq, feeds):
+    """[NUNIQ, feeds] frames in HBM laid out like bench.py's `dev` tensor: step k's batch = the feeds' frames of that time step"""
+    from hipmem import DeviceArray, _rt
+
+    fb = uniq[0].nbytes
+    d = DeviceArray.__new__(DeviceArray)
+    import ctypes as C
+
+    p = C.c_void_p()
+    assert _rt().hipMalloc(C.byref(p), fb * NUNIQ * feeds) == 0
+    d.ptr, d.nbytes = p.value, fb * NUNIQ * feeds
+    for k in range(NUNIQ):
+        for f in range(feeds):
+            src = uniq[synth.stream_frame_index(k, f, NUNIQ)]
+            assert _rt().hipMemcpy(d.ptr + (k * feeds + f) * fb, src.ctypes.data, fb, 1) == 0
+    return d
+
+
+def floored_rects(best, w, h):
+    """facetrackr.js:101-106 (Math.floor of the detection) with bench.py's stand-in rect for a feed without a face"""
+    fl = np.floor(np.stack([best["x"], best["y"], best["width"], best["height"]], axis=1)).astype(np.int64)
+    return [tuple(int(v) for v in fl[f]) if best["neighbors"][f] > 0 and best["confidence"][f] > -10 else (w // 4, h // 4, w // 2, h // 2)
+            for f in range(len(best))]
+
+
+@pytest.mark.parametrize("feeds", [8, 3])
+def test_c5_shape_feeds_in_one_context_vs_oracle(cascade, feeds):
+    """61 steps = two 30-step cycles + the third cycle's detect: steps 0 / 30 / 60 detect (the 2nd is captured into a hipGraph, the
+    3rd replays it), all others track.  Every detect step's best face per feed == the oracle's bit for bit; every track object within
+    +-1 px / +-0.5 deg (sizes equal) and, the reduction tree being fixed, bit-exact — counted."""
+    K, steps = feeds, 61
+    uniq = synth.stream_feed_frames(NUNIQ, W, H, 0)
+    c = Context()  # first: ht_create selects the device
+    dev = c5_device_steps(uniq, K)
+    sbytes = K * W * H * 4
+    try:
+        c.set_geometry(W, H, K)
+        c.camshift_reserve(K)
+        want_best = {}  # unique frame -> oracle best face (a feed's detect frames repeat every cycle)
+        oracles = [None] * K
+        stats = []
+        for i in range(steps):
+            c.bind_device(dev.ptr + (i % NUNIQ) * sbytes, K)
+            if i % 30 == 0:
+                c.detect_enqueue(0)
+                best = c.detect_collect_best(1)[0].copy()
+                rects = floored_rects(best, W, H)
+                c.camshift_init(rects)
+                for f in range(K):
+                    u = synth.stream_frame_index(i, f, NUNIQ)
+                    if u not in want_best:
+                        want_best[u] = ho.best_faces(uniq[u : u + 1], cascade.blob, 1)[0]
+                    for k in ("x", "y", "width", "height", "confidence", "neighbors"):
+                        assert best[k][f] == want_best[u][k], (i, f, k, best[f], want_best[u])
+                    assert best["neighbors"][f] > 0, (i, f)
+                    oracles[f] = ho.Camshift(True)
+                    oracles[f].init_tracker(uniq[u], rects[f])
+            else:
+                assert c.camshift_track(K, calc_angles=True, fetch=False) is not None  # enqueue only
+                got = c.camshift_track_collect(K)
+                for f in range(K):
+                    sw, to = oracles[f].track(uniq[synth.stream_frame_index(i, f, NUNIQ)])
+                    cs_check(got[f], sw, to, stats, where=("c5", K, f, i))
+        assert c.graph_launches >= 2, c.graph_launches  # step 30: capture + launch, step 60: replay
+        assert len(stats) == K * (steps - 3)
+        cs_all_exact(stats, f"C5 shape, {K} x 1080p feeds in one context, {steps} steps")
+    finally:
+        c.close()
+        dev.free()
+
+
+@pytest.mark.parametrize("wb", [False, True], ids=["plain", "whitebalance"])
+@pytest.mark.parametrize("w,h,n", [(320, 240, 3), (322, 241, 2), (1920, 1080, 1)])
+def test_graph_replay_equals_plain_enqueue(cascade, wb, w, h, n):
+    """a replayed detect graph (same frames pointer / count / flags from the third enqueue on) must give the same raw
+    hits, counts and whitebalance sums as plain launches (a context with option graph_max_frames=0), incl. widths that are not multiples of 4
+    (whitebalance in its own pass) — and must actually have replayed."""
+    from headtrackr_amd.native import HT_DETECT_WHITEBALANCE
+
+    flags = HT_DETECT_WHITEBALANCE if wb else 0
+    frames = synth.mixed_batch(max(n, 3), w, h, seed0=91)[-n:]  # ends on a face frame for n == 1
+    plain = Context(options="graph_max_frames=0")
+    c = Context()
+    try:
+        for cx in (plain, c):
+            cx.set_geometry(w, h, n)
+            cx.upload(frames)
+        plain.detect_enqueue(flags)
+        want, want_counts = plain.detect_collect()
+        want_wb = plain.detect_whitebalance() if wb else None
+        assert plain.graph_launches == 0
+        for rep in range(4):
+            c.detect_enqueue(flags)
+            got, counts = c.detect_collect()
+            assert got.tobytes() == want.tobytes() and np.array_equal(counts, want_counts), rep
+            if wb:
+                assert np.array_equal(c.detect_whitebalance(), want_wb), rep
+        assert c.graph_launches == 3  # 1st plain, 2nd captured + launched, 3rd / 4th replayed
+        if wb:
+            assert np.array_equal(want_wb, np.array([ho.whitebalance(f) for f in frames]))
+        # fewer frames bound into the same context: another graph key (the count is part of it), results still right
+        if n > 1:
+            c.set_geometry(w, h, n - 1)
+            c.upload(frames[: n - 1])
+            for rep in range(3):
+                c.detect_enqueue(flags)
+                got, counts = c.detect_collect()
+                assert np.array_equal(counts, want_counts[: n - 1]) and got.tobytes() == want[: int(want_counts[: n - 1].sum())].tobytes()
+    finally:
+        plain.close()
+        c.close()

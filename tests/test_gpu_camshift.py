@@ -41,19 +41,8 @@ atexit.register(_write_parity)
 @pytest.fixture(scope="module", params=["chunked", "fused"])
 def ctx(request):
     """every test of this module runs on both camshift schedules: chunk histograms + one mean-shift workgroup per stream (few
-    streams), and the single-launch kernel that is chosen for >= 192 streams (forced here with HT_DEBUG_CS_FUSED_MIN=1)"""
-    import os
-
-    old = os.environ.get("HT_DEBUG_CS_FUSED_MIN")
-    if request.param == "fused":
-        os.environ["HT_DEBUG_CS_FUSED_MIN"] = "1"
-    else:
-        os.environ["HT_DEBUG_CS_FUSED_MIN"] = "1000000"
-    c = Context()  # the knob is read once, in ht_create
-    if old is None:
-        os.environ.pop("HT_DEBUG_CS_FUSED_MIN", None)
-    else:
-        os.environ["HT_DEBUG_CS_FUSED_MIN"] = old
+    streams), and the single-launch kernel that is chosen for >= 192 streams (forced here with option cs_fused_min=1)"""
+    c = Context(options="cs_fused_min=1" if request.param == "fused" else "cs_fused_min=1000000")
     yield c
     c.close()
 
@@ -153,7 +142,7 @@ def test_batch_of_streams_vs_oracle(ctx):
 
 @pytest.mark.parametrize("w,h,n", [(1920, 1080, 1), (641, 363, 3), (61, 45, 2)], ids=["1080p-1stream", "odd-641x363", "tiny-61x45"])
 @pytest.mark.parametrize("fused", [False, True], ids=["chunked", "fused"])
-def test_frame_sizes_and_chunking(w, h, n, fused, monkeypatch):
+def test_frame_sizes_and_chunking(w, h, n, fused):
     """The histogram pass cuts a frame into chunk histograms (127 for one 1080p stream, 1 for a tiny frame) and handles
     pixel counts that are not multiples of 4; the mean-shift kernel adds the chunks.  Same answers as the oracle."""
     steps = 4
@@ -163,8 +152,7 @@ def test_frame_sizes_and_chunking(w, h, n, fused, monkeypatch):
         cx, cy = w // 2 + 3 * s, h // 2 - 2 * s
         seqs.append([synth.blob_frame(w, h, cx + k, cy + k // 2, a, b, (4, 3, 5), (200, 60, 40), seed=77 + 13 * s + k) for k in range(steps)])
         rects.append((cx - a, cy - b, 2 * a, 2 * b))
-    monkeypatch.setenv("HT_DEBUG_CS_FUSED_MIN", "1" if fused else "1000000")
-    c = Context()
+    c = Context(options="cs_fused_min=1" if fused else "cs_fused_min=1000000")
     try:
         c.set_geometry(w, h, n)
         c.camshift_reserve(n)
@@ -266,16 +254,14 @@ def test_six_contexts_track_1080p_feeds_concurrently():
                 d.free()
 
 
-def test_cluster_barrier_timeout_is_a_status_code(monkeypatch):
+def test_cluster_barrier_timeout_is_a_status_code():
     """The cluster barrier is a bounded spin: with a budget of one cycle every workgroup that arrives early gives up at once; the
     call must come back with HT_ERR_STATE (never hang), and the context must work again afterwards."""
     from headtrackr_amd.api import HtError
 
     w, h = 1920, 1080
     feeds, rects = _feeds_1080p(1, 3)
-    monkeypatch.setenv("HT_DEBUG_CS_BARRIER_BUDGET", "1")
-    c = Context()
-    monkeypatch.delenv("HT_DEBUG_CS_BARRIER_BUDGET")
+    c = Context(options="cs_barrier_budget=1")
     good = Context()
     try:
         for cx in (c, good):

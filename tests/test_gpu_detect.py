@@ -121,11 +121,10 @@ def test_pyramid_planes_random_geometries(ctx, w, h):
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (38, 30)])
-def test_pyramid_without_tail_kernel(w, h, monkeypatch):
-    """The last (tiny) generations are built by k_resample_tail by default; with HT_DEBUG_RS_NOTAIL every generation goes
+def test_pyramid_without_tail_kernel(w, h):
+    """The last (tiny) generations are built by k_resample_tail by default; with option rs_notail every generation goes
     through k_resample.  Both must produce the oracle's planes bit for bit."""
-    monkeypatch.setenv("HT_DEBUG_RS_NOTAIL", "1")
-    c = Context()
+    c = Context(options="rs_notail=1")
     try:
         _check_pyramid(c, w, h)
     finally:
@@ -163,12 +162,11 @@ def test_gray_in_r_entry(ctx, cascade):
 
 @pytest.mark.parametrize("table", ["0", "1"], ids=["binary64-tail", "table-tail"])
 @pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (38, 30)])
-def test_pyramid_both_tail_kernels(w, h, table, monkeypatch):
+def test_pyramid_both_tail_kernels(w, h, table):
     """The last generations are built by one of two tail kernels, chosen by batch size: the round-1 one (taps re-derived in
     registers, binary64 lerps) and the table-driven one (host tap tables, binary32 estimate + binary64 fallback, integer box
     means).  Forced here on the same inputs: every plane equals the oracle's with either."""
-    monkeypatch.setenv("HT_DEBUG_RS_TAILTABLE", table)
-    c = Context()
+    c = Context(options=f"rs_tailtable={table}")
     try:
         _check_pyramid(c, w, h)
     finally:
@@ -176,14 +174,14 @@ def test_pyramid_both_tail_kernels(w, h, table, monkeypatch):
 
 
 @pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (1280, 720), (1920, 1080)])
-def test_pyramid_fast_paths_equal_the_declared_binary64_sequence(w, h, monkeypatch):
+def test_pyramid_fast_paths_equal_the_declared_binary64_sequence(w, h):
     """k_resample evaluates a pixel in binary32 and falls back to the declared binary64 sequence next to a rounding boundary;
-    exact 2:1 canvases are integer box means.  HT_DEBUG_RS_NOFAST keeps every pixel on the binary64 sequence: all planes of
+    exact 2:1 canvases are integer box means.  Option rs_nofast keeps every pixel on the binary64 sequence: all planes of
     both builds must be identical (and both equal the oracle, test_pyramid_planes_vs_oracle)."""
     frames = np.stack([synth.noise_frame(w, h, 11), synth.smooth_frame(w, h, 12), synth.face_frame(w, h, [(w // 8, h // 8, min(w, h) // 2)])])
 
-    def planes():
-        c = Context()
+    def planes(options=None):
+        c = Context(options=options)
         try:
             c.set_geometry(w, h, len(frames))
             c.upload(frames)
@@ -200,8 +198,7 @@ def test_pyramid_fast_paths_equal_the_declared_binary64_sequence(w, h, monkeypat
             c.close()
 
     fast = planes()
-    monkeypatch.setenv("HT_DEBUG_RS_NOFAST", "1")
-    slow = planes()
+    slow = planes("rs_nofast=1")
     assert len(fast) == len(slow) == 3 * 120 and fast == slow
 
 
@@ -233,12 +230,11 @@ def test_full_batch_is_frame_independent(ctx, cascade):
     assert sum(int(counts[i] > 0) for i in range(2, n, 3)) > n // 3 * 0.9
 
 
-def test_early_scan_on_second_stream(cascade, monkeypatch):
-    """HT_DEBUG_EARLY_SCAN=1: scale 0 is scanned on a second HIP stream while the late pyramid generations are built; same hits
+def test_early_scan_on_second_stream(cascade):
+    """Option early_scan=1: scale 0 is scanned on a second HIP stream while the late pyramid generations are built; same hits
     (two tile launches + event dependencies instead of one launch)."""
     frames = synth.mixed_batch(12, 320, 240, seed0=1234)
-    monkeypatch.setenv("HT_DEBUG_EARLY_SCAN", "1")
-    c = Context()
+    c = Context(options="early_scan=1")
     try:
         for _ in range(3):  # back-to-back batches on one context: the next batch must not overtake the second stream
             hits, _ = c.detect_raw(frames)
@@ -304,15 +300,13 @@ def test_best_faces_matches_per_frame_grouping(ctx):
 
 
 @pytest.mark.parametrize("deep_v", ["4", "2"])
-def test_exact_tie_fallback_path(ctx, cascade, deep_v, monkeypatch):
+def test_exact_tie_fallback_path(ctx, cascade, deep_v):
     """The integer stage decisions fall back to the sequential binary64 sum on an exact tie with the threshold — a case the
-    built-in cascade practically never produces.  HT_DEBUG_FORCE_EXACT makes every decision take that fallback (tile kernel
+    built-in cascade practically never produces.  Option force_exact makes every decision take that fallback (tile kernel
     incl. its sparse phase, and both deep kernels): results must be unchanged."""
     frames = synth.mixed_batch(6, 320, 240, seed0=1234)
     want, _ = ctx.detect_raw(frames)
-    monkeypatch.setenv("HT_DEBUG_FORCE_EXACT", "1")
-    monkeypatch.setenv("HT_DEBUG_DEEP_V", deep_v)
-    forced = Context()  # the knobs are read once, in ht_create
+    forced = Context(options=f"force_exact=1,deep_v={deep_v}")
     try:
         got, _ = forced.detect_raw(frames)
     finally:

@@ -75,6 +75,51 @@ def test_c4_batch_shape_every_frame_vs_oracle(cascade):
         c.close()
 
 
+@pytest.mark.parametrize("rank", [0, 1])
+def test_c4_bench_frames_all_128_distinct_vs_oracle(cascade, rank):
+    """The frames bench.py TIMES at C4: all 128 distinct 1280x720 frames of a rank's batch (seed 1234 + 1000 * rank; ranks 0 and 1
+    here — rank r > 0 of an N-GPU run times frames no other test has seen), in one batch like the bench: every frame's raw hits
+    (indices + binary64 confidence bits), the per-stage window counts and the best face per frame == the oracle's."""
+    w, h, n = 1280, 720, 128
+    frames = synth.mixed_batch(n, w, h, seed0=1234 + 1000 * rank)
+    stage_ref = np.zeros(cascade.count + 1, dtype=np.int64)
+    ref = []
+    for i in range(n):
+        sp = np.zeros(cascade.count + 1, dtype=np.int64)
+        ref.append(ho.detect_raw(frames[i], cascade.blob, stage_pass=sp))
+        stage_ref += sp
+    c = Context()
+    try:
+        c.set_geometry(w, h, n)
+        c.upload(frames)
+        c.detect_enqueue(HT_SCAN_STATS)
+        hits, counts = c.detect_collect(cap=1 << 17)
+        assert np.array_equal(c.stage_counts().astype(np.int64), stage_ref)
+        starts = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        assert len(hits) == starts[-1] == sum(len(r) for r in ref) and len(hits) > 500
+        for i in range(n):
+            got, r = hits[starts[i] : starts[i + 1]], ref[i]
+            assert len(got) == len(r), f"frame {i}"
+            assert np.all(got["frame"] == i)
+            for k in ("scale", "q", "x", "y"):
+                assert np.array_equal(got[k].astype(np.int64), r[k].astype(np.int64)), (i, k)
+            assert np.array_equal(got["sum"].view(np.uint64), r["sum"].view(np.uint64)), f"frame {i}: confidence bits"
+        c.detect_enqueue(0)  # the bench's timed call
+        best, nhits = c.detect_collect_best(1)
+        assert nhits == len(hits)
+        want = np.zeros(n, dtype=ho.RECT_DTYPE)
+        for i in range(n):
+            g = ho.group(ho.hits_to_rects(ref[i]), 1)
+            want[i]["confidence"] = -10000.0
+            for k in range(len(g)):
+                if k == 0 or g[k]["confidence"] > want[i]["confidence"]:
+                    want[i] = g[k]
+        for k in ("x", "y", "width", "height", "confidence", "neighbors"):
+            assert np.array_equal(best[k], want[k]), k
+    finally:
+        c.close()
+
+
 def test_c4_strong_shape_1024_frames_on_one_gpu(cascade):
     """The `c4_strong` sub-record of the bench line: all 1024 x 1280x720 frames of BASELINE.json configs[3] in ONE batch on one GPU
     (15 x the tile count, survivor queue and hit volume of the 128-frame shape; 1.03 G windows): every frame's raw hits — indices and
@@ -202,17 +247,16 @@ def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
 
 
 @pytest.mark.parametrize("fused", [False, True], ids=["chunked", "fused"])
-def test_camshift_histograms_bin_for_bin(fused, monkeypatch):
+def test_camshift_histograms_bin_for_bin(fused):
     """camshift.Histogram (camshift.js:49-72): the model histogram of initTracker and the full-frame histogram of track(),
     read back from the device, equal the oracle's in every one of the 4096 bins — incl. a rect reaching outside the frame
     (transparent black -> bin 0), an odd pixel count, and a frame cut into many chunk histograms; on both schedules (the
-    single-launch kernel keeps its histogram in LDS and only writes it out under HT_DEBUG_CS_KEEP_HIST)."""
-    monkeypatch.setenv("HT_DEBUG_CS_FUSED_MIN", "1" if fused else "1000000")
-    monkeypatch.setenv("HT_DEBUG_CS_KEEP_HIST", "1")
+    single-launch kernel keeps its histogram in LDS and only writes it out with option cs_keep_hist)."""
+    opts = f"cs_fused_min={1 if fused else 1000000},cs_keep_hist=1"
     for (w, h, rect) in [(320, 240, (100, 60, 90, 80)), (321, 243, (-10, -5, 60, 70)), (1280, 720, (1200, 650, 200, 200))]:
         a = synth.blob_frame(w, h, w // 2, h // 2, w // 6, h // 8, (4, 3, 5), (200, 60, 40), seed=5)
         b = synth.blob_frame(w, h, w // 2 + 3, h // 2 + 2, w // 6, h // 8, (4, 3, 5), (200, 60, 40), seed=6)
-        c = Context()
+        c = Context(options=opts)
         try:
             c.set_geometry(w, h, 1)
             c.camshift_reserve(1)
@@ -297,13 +341,12 @@ def test_collect_reports_the_enqueued_batch(cascade):
         c.close()
 
 
-def test_allgather_best_faces_over_rccl(cascade, monkeypatch):
+def test_allgather_best_faces_over_rccl(cascade):
     """The single-process exchange step (ht_allgather_best_faces): one context per visible GPU, frames block-sharded, every
     rank's best-face rects all-gathered over RCCL and checked to be identical on every GPU.  With one GPU the call still goes
-    through dlopen(librccl) + ncclCommInitAll + ncclAllGather (HT_DEBUG_FORCE_RCCL)."""
+    through dlopen(librccl) + ncclCommInitAll + ncclAllGather (option force_rccl)."""
     from headtrackr_amd import api, distributed as hd
 
-    monkeypatch.setenv("HT_DEBUG_FORCE_RCCL", "1")
     ndev = api.device_count()
     assert ndev >= 1
     n = 6 * ndev + (1 if ndev > 1 else 0)
@@ -313,7 +356,7 @@ def test_allgather_best_faces_over_rccl(cascade, monkeypatch):
     try:
         for r in range(ndev):
             a, b = hd.shard_range(n, r, ndev)
-            c = Context(device=r)
+            c = Context(device=r, options="force_rccl=1")
             ctxs.append(c)
             hits, counts = c.detect_raw(frames[a:b])
             best = np.zeros(per, dtype=api.RECT_DTYPE)

@@ -27,7 +27,7 @@ def test_facade_exports_and_host_grouping():
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"], out["errors"]
-    assert out["abi"] == 1
+    assert out["abi"] == 2
 
 
 @pytest.mark.gpu

@@ -130,7 +130,10 @@ def dominant_roofline(per_step_ms, launches_per_step, bytes_per_step, extra=None
     launch / average launch duration)."""
     dom = max(per_step_ms, key=per_step_ms.get)
     ach = bytes_per_step / (per_step_ms[dom] * 1e-3) / 1e9
-    r = dict(bound="hbm", kernel=dom, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
+    # kernels within 5 % of the dominant one's time per step are named with it (C2: resample's launches and scan_tiles trade places from run to run)
+    co = {k: dict(kernel_ms_per_step=round(v, 5), frac=round(bytes_per_step / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 5))
+          for k, v in per_step_ms.items() if k != dom and v >= 0.95 * per_step_ms[dom]}
+    r = dict(bound="hbm", kernel=dom, co_dominant=co, achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5), traffic=None,
              kernel_ms_per_step=round(per_step_ms[dom], 5), launches_per_step=round(launches_per_step[dom], 2),
              avg_launch_ms=round(per_step_ms[dom] / max(launches_per_step[dom], 1e-9), 5), dominant="largest device time per step (sum of its launches)")
     if extra:
@@ -229,9 +232,11 @@ def device_copy_ceiling(torch):
 
 
 def load_traffic(workload):
+    """profiles/traffic.json: HBM bytes per STEP and kernel timer name, summed over the launches of every kernel the timer covers
+    (`resample` = the k_resample launches + k_resample_tail), from the committed rocprofv3 counter passes (tools/collect_profiles.py)."""
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     try:
-        return json.load(open(tf)).get(workload, {})
+        return json.load(open(tf)).get(workload, {}).get("per_step", {})
     except Exception:
         return {}
 
@@ -240,7 +245,7 @@ def load_traffic(workload):
 # detect workloads (c2, c4)
 
 
-def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, cpu_seconds=0.0, prewarm=0.0, full=True):
+def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, cpu_seconds=0.0, prewarm=0.0, full=True, gather=None, unique=0):
     """One detect workload: K timed steps (barrier + synchronize on both sides, max over ranks), then — on rank 0 — the live
     HIP-event roofline of the dominant kernel and the CPU baseline.  Returns the record (rank 0) or None."""
     torch, dist, rank, world, local = env.torch, env.dist, env.rank, env.world, env.local
@@ -258,7 +263,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
         total = nf * world
         f0 = rank * nf
     nf_max = -(-total // world)
-    uniq = min(a.unique or (128 if name == "c4" else 256), nf)  # C4: every frame of the per-GPU batch is distinct (round 2 tiled 12 unique frames); the 1024-frame strong-scaling batch repeats the 128
+    uniq = min(unique or a.unique or (128 if name == "c4" else 256), nf)  # C4: every frame of the per-GPU batch is distinct (round 2 tiled 12 unique frames); the 1024-frame strong-scaling batch repeats the 128
     # frame g of the job is synthetic frame g mod uniq' of the N/S/F mix, seeded per rank
     base = synth.mixed_batch(uniq, W, H, seed0=1234 + 1000 * rank)
     dev_uniq = torch.from_numpy(base).cuda()
@@ -276,7 +281,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     # the exchange step's buffers, one set per batch in flight: pinned host records -> device records -> gathered table.  Nothing in it
     # blocks the host: the copy is asynchronous, the collective is enqueued on RCCL's stream, and a set is only reused `depth` steps later
     # (its event is checked first — by then it has long completed).
-    gather_on = world > 1 or os.environ.get("HT_BENCH_FORCE_GATHER") == "1"  # the env knob exercises this path on a 1-GPU box
+    gather_on = world > 1 or bool(gather)  # gather=True runs the exchange step on one GPU too (sub.gather_n1: what a step pays for it)
     xch = {}
     if gather_on:
         for cx in ctxs:
@@ -305,7 +310,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
             x["pin"].numpy()[:] = rec
             x["dev"].copy_(x["pin"], non_blocking=True)
             x["ev"].record()
-            state["gathered"] = hd.allgather_records(x["dev"], world, nf_max, out=x["out"])
+            state["gathered"] = hd.allgather_records(x["dev"], world, nf_max, out=x["out"], force_collective=bool(gather))
             state["rec"] = rec
         return best
 
@@ -367,9 +372,12 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     all_traffic = load_traffic(name)
     roofline = dominant_roofline(per_step, {k: v["launches"] / psteps for k, v in kt.items()}, b_detect * nf,
                                  dict(algorithmic_bytes_per_frame=b_detect, frames_per_step=nf))
-    # PMC traffic of the dominant kernel per step (all its launches), from the committed rocprofv3 counter passes
-    tr = all_traffic.get(roofline["kernel"]) if (nf, scaling) == (nf_default, "weak") else None  # profiles/traffic.json: bytes per launch
-    roofline["traffic"] = round(tr * roofline["launches_per_step"]) if tr else None
+    # PMC traffic per step (every launch's own counters summed), from the committed rocprofv3 counter passes — only for the shape they were taken at
+    if (nf, scaling) != (nf_default, "weak"):
+        all_traffic = {}
+    roofline["traffic"] = all_traffic.get(roofline["kernel"])
+    for k in roofline["co_dominant"]:
+        roofline["co_dominant"][k]["traffic"] = all_traffic.get(k)
     dev_ms = sum(per_step.values())
     rec = {
         "value": round(fps, 2), "unit": "frames/s", "steps": steps, "warmup": warmup, **spread, "scaling": scaling,
@@ -385,7 +393,9 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     own = {"gray": 5 * W * H * nf, "resample": 2 * (P - W * H) * nf, "scan_tiles": P * nf}
     rec["kernel_ms_per_step"] = {k: round(v, 5) for k, v in per_step.items()}
     rec["kernel_rooflines"] = {k: dict(own_bytes_per_step=own[k], gbs=round(own[k] / (per_step[k] * 1e-3) / 1e9, 1),
-                                       frac=round(own[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)) for k in own if k in per_step}
+                                       frac=round(own[k] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), traffic=all_traffic.get(k)) for k in own if k in per_step}
+    if all_traffic:
+        rec["path_traffic_over_algorithmic"] = round(sum(v for v in all_traffic.values() if v) / (b_detect * nf), 3)
     rec["device_ms_per_step"] = round(dev_ms, 5)
     # whole-path figures (every kernel of a step): device time, and the wall clock of the timed region
     rec["path_hbm_gbs"] = round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2)
@@ -691,12 +701,42 @@ def stream_bench(env, a, feeds=1, steps=300, warm_cycles=1, cpu_seconds=0.0):
     fps = world * K * steps / dt
     fps_p = world * K * steps / dt_p
     lr = last["r"]
+    # parity in the same run (after the timed regions): one 31-step cycle exactly as timed above — bind a new set every step, detect
+    # (graph replay by now) + initTracker on step 0 / 30, enqueue-only track + collect otherwise — every feed against the oracle
+    from oracle import ht_oracle as ho
+
+    exact = tot = 0
+    det_ok = det_tot = 0
+    oracles = [None] * K
+    replays0 = ctx.graph_launches
+    for i in range(31):
+        ctx.bind_device(dev.data_ptr() + (i % nuniq) * sbytes, K)
+        enqueue(i)
+        got = collect(i)
+        for f in range(K):
+            fr = uniq[synth.stream_frame_index(i, f, nuniq)]
+            if is_detect(i):
+                w = ho.best_faces(fr[None], ctx.cascade.blob, 1)[0]
+                det_tot += 1
+                det_ok += int(all(got[k][f] == w[k] for k in ("x", "y", "width", "height", "confidence", "neighbors")))
+                rect = [int(np.floor(got[k][f])) for k in ("x", "y", "width", "height")] if got["neighbors"][f] > 0 and got["confidence"][f] > -10 else [W // 4, H // 4, W // 2, H // 2]
+                oracles[f] = ho.Camshift(True)
+                oracles[f].init_tracker(fr, rect)
+            else:
+                sw, to = oracles[f].track(fr)
+                g = got[f]
+                tot += 1
+                exact += int([int(g["sw_x"]), int(g["sw_y"]), int(g["sw_width"]), int(g["sw_height"])] == list(sw) and
+                             all(float(g[q]) == to[q] for q in ("x", "y", "width", "height")) and abs(float(g["angle"]) - to["angle"]) < 1e-6)
+    parity = dict(parity_exact=f"{exact}/{tot}", parity_detect_exact=f"{det_ok}/{det_tot}", parity_graph_replays=int(ctx.graph_launches - replays0),
+                  parity_note="one 31-step cycle of this run's own loop (bind per step, graph-replayed detect + initTracker on steps 0 / 30, enqueue-only track + collect) vs oracle/ht_oracle.c: "
+                              "best faces bit-exact; track(): search window, x, y, width, height bit-exact, angle to 1e-6 rad (61 steps, also from Node: tests/test_gpu_c5.py)")
     rec = {
         "value": round(fps, 2), "unit": "frames/s", "steps": steps, "warmup": warm_cycles, **spread, "scaling": "weak",
         "config": {"workload": f"C5: {K} frame-synchronous 1920x1080 RGBA feed(s) per GPU as one batch of {K} frames per time step; detect + initTracker on steps 0, 30, 60, ..., camshift.track otherwise",
                    "feeds_per_gpu": K, "width": W, "height": H, "frames": "resident in HBM before the timed region (value); host -> GPU every step in pcie_inclusive",
                    "parallelism": f"{world * K} feed(s): {K} per GPU in one context / batch, {world} GPU(s), no collective"},
-        "per_feed_fps": round(fps / (world * K), 2),
+        "per_feed_fps": round(fps / (world * K), 2), **parity,
         "pcie_inclusive": {"value": round(fps_p, 2), "unit": "frames/s", **spread_p, "per_feed_fps": round(fps_p / (world * K), 2),
                            "h2d_gbs": round(fps_p / world * fbytes / 1e9, 2), "note": "double-buffered pinned ingest; 8.29 MB per frame: the link (~56 GB/s measured) allows ~6.8 k frames/s per GPU whatever the kernels do"},
         "latency_note": "latency_ms: one time step strictly in turn incl. PCIe: upload the feeds' frames, process, results on the host (separate untimed pass)",
@@ -734,8 +774,17 @@ def js_host_bench(seconds=2.0):
             tr = os.path.join(td, "track.raw")
             np.stack([synth.face_frame(W, H, [(90 + 2 * k, 50 + k, 96)]) for k in range(nt)]).tofile(tr)
             r = subprocess.run([node, script, str(seconds), c2, str(n), tr, str(nt)], capture_output=True, text=True, timeout=seconds * 20 + 240)
-        j = json.loads(r.stdout.strip().splitlines()[-1])
-        j["config"] = {"workload": f"JS host (Node + N-API addon): {n} x {W}x{H} detect per batch (the C2 frames) and facetrackr.Tracker.track() on a {W}x{H} canvas with one drifting face"}
+            j = json.loads(r.stdout.strip().splitlines()[-1])
+            # C5 from the JavaScript host: 8 frame-synchronous 1080p feeds, DeviceBatch.detectStep / trackStep (tests/js/c5_stream.js)
+            try:
+                uq = os.path.join(td, "uniq.raw")
+                synth.stream_feed_frames(30, 1920, 1080, 0).tofile(uq)
+                r5 = subprocess.run([node, os.path.join(ROOT, "tests", "js", "c5_stream.js"), "bench", uq, "30", "8", str(seconds)], capture_output=True, text=True, timeout=seconds * 20 + 240)
+                j["c5"] = json.loads(r5.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                j["c5"] = {"error": f"{type(e).__name__}: {e}"}
+        j["config"] = {"workload": f"JS host (Node + N-API addon): {n} x {W}x{H} detect per batch (the C2 frames), facetrackr.Tracker.track() on a {W}x{H} canvas with one drifting face, "
+                                   "and the C5 loop (8 x 1080p feeds per step) through ccv.DeviceBatch.detectStep / trackStep"}
         return j
     except Exception as e:
         return {"error": f"{type(e).__name__}: {e}"}
@@ -814,6 +863,11 @@ def main():
     stub = os.environ.get("HT_BENCH_STUB") == "1"
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(a)  # does not return
+    # The ONE JSON line owns stdout: native libraries print there too (RCCL's version banner sits in C stdio's buffer until the process
+    # exits and would land BEHIND the line) — file descriptor 1 is handed to stderr for everything but the line itself.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -828,7 +882,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         line = stub_bench(Env(torch, dist, rank, world, local, stub=True), a)
         if rank == 0:
-            print(json.dumps(line), flush=True)
+            print(json.dumps(line), file=line_out, flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -863,17 +917,48 @@ def main():
             sub[tag] = detect_bench(env, a, "c4", SUB_STEPS["c4"], 10, cpu_seconds=a.cpu_seconds, prewarm=0.1, full=False)
             sub["c4_strong"] = detect_bench(env, a, "c4", SUB_STEPS["c4_strong"], 4, scaling="strong", cpu_seconds=0, full=False)
             sub["c3"] = c3_bench(env, a, SUB_STEPS["c3"], 2, a.cpu_seconds * 0.7)
+            # C2 with a working set far beyond the 256 MB Infinity Cache (1024 frames: 315 MB of RGBA + 450 MB of pyramid per batch in
+            # flight): the "HBM" rates of the 256-frame headline are partly MALL hits, this point says what the path does without them
+            sub["c2_large"] = detect_bench(env, a, "c2", 60, 6, frames_per_gpu=1024, cpu_seconds=0, prewarm=0.1, full=False, unique=256)
+            # BASELINE.json configs[4] is 8 feeds over the node: 8 / N per GPU (N = 1: all eight on the one GPU)
+            feeds_per_gpu = max(1, 8 // world)
             one = stream_bench(env, a, feeds=1, steps=SUB_STEPS["c5"], cpu_seconds=a.cpu_seconds * 0.7)
-            many = stream_bench(env, a, feeds=8, steps=SUB_STEPS["c5"], cpu_seconds=0)
+            many = stream_bench(env, a, feeds=feeds_per_gpu, steps=SUB_STEPS["c5"], cpu_seconds=0) if feeds_per_gpu > 1 else one
             if rank == 0:
-                many["one_feed"] = one
-                many["feeds_8_vs_1"] = round(many["value"] / one["value"], 2)
-                many["feeds_8_vs_1_pcie_inclusive"] = round(many["pcie_inclusive"]["value"] / one["pcie_inclusive"]["value"], 2)
-                many["cpu_baseline"] = one["cpu_baseline"]
-                many["vs_cpu"] = round(many["value"] / one["cpu_baseline"]["value"], 1) if one.get("cpu_baseline") else None
+                if many is not one:
+                    many["one_feed"] = one
+                    many["feeds_vs_1"] = round(many["value"] / one["value"] * 1.0, 2)
+                    many["feeds_vs_1_pcie_inclusive"] = round(many["pcie_inclusive"]["value"] / one["pcie_inclusive"]["value"], 2)
+                    many["cpu_baseline"] = one["cpu_baseline"]
+                    many["vs_cpu"] = round(many["value"] / one["cpu_baseline"]["value"], 1) if one.get("cpu_baseline") else None
             sub["c5"] = many
             if rank == 0 and world == 1:
                 sub["js_host"] = js_host_bench(2.0)
+            if world == 1:
+                # what the exchange step costs a step, measured where one GPU can measure it: the same C2 / C4 blocks with the all-gather of
+                # best-face records forced through a 1-rank RCCL group (event wait, pack, pinned copy, H2D, ncclAllGather on RCCL's stream)
+                t_init = time.perf_counter()
+                try:
+                    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    import socket
+
+                    sk = socket.socket()
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+                    sk.close()
+                    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+                    g = {}
+                    for nm, st_, key in (("c2", 200, None), ("c4", SUB_STEPS["c4"], "c4_1gpu")):
+                        r = detect_bench(env, a, nm, st_, 10, cpu_seconds=0, prewarm=0.1, full=False, gather=True)
+                        ref = sub[key] if key else None
+                        g[nm] = dict(ms_per_step=r["ms_per_step"], ms_per_step_min=r["ms_per_step_min"], ms_per_step_max=r["ms_per_step_max"], value=r["value"],
+                                     allgather_verified=r.get("allgather_verified"), without_exchange_ms_per_step=ref["ms_per_step"] if ref else None)
+                    g["rccl_init_and_runs_s"] = round(time.perf_counter() - t_init, 1)
+                    g["what"] = "the timed C2 / C4 blocks with every step's exchange forced on ONE GPU: event wait + pack + pinned copy + H2D + all_gather_into_tensor on a 1-rank RCCL group"
+                    sub["gather_n1"] = g
+                    dist.destroy_process_group()
+                except Exception as e:  # never lose the line to the optional leg
+                    sub["gather_n1"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         copy_gbs = device_copy_ceiling(torch)
         for r in [prim] + [v for v in sub.values() if v]:
@@ -884,12 +969,18 @@ def main():
                 "ms_per_step": prim["ms_per_step"], "higher_is_better": True, "scaling": prim["scaling"], "vs_baseline": None, "dtype": "u8",
                 "data": "synthetic", "launched_by_bench": os.environ.get("HT_BENCH_LAUNCHED") == "1"}
         line.update({k: v for k, v in prim.items() if k not in line})
+        if sub.get("gather_n1") and "c2" in sub["gather_n1"]:
+            g = sub["gather_n1"]
+            g["c2"]["without_exchange_ms_per_step"] = prim["ms_per_step"]
+            for nm in ("c2", "c4"):
+                if g[nm].get("without_exchange_ms_per_step"):
+                    g[nm]["exchange_cost_frac"] = round(g[nm]["ms_per_step"] / g[nm]["without_exchange_ms_per_step"] - 1.0, 4)
         if sub:
             line["sub"] = sub
             if sub.get("c4_1gpu") and sub["c4_1gpu"].get("vs_cpu"):
                 line["north_star_720p_vs_reference_js"] = sub["c4_1gpu"]["vs_cpu"]  # target: >= 30x on 1280x720 detect at 1 GPU
         line["bench_wall_s"] = round(time.perf_counter() - t_run, 1)
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=line_out, flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -72,7 +72,7 @@ def build_addon(force: bool = False, verbose: bool = False) -> str | None:
     deps = [src, os.path.join(ROOT, "include", "headtrackr_hip.h")]
     if force or _newer(ADDON, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", "/usr/include/node", "-I", os.path.join(ROOT, "include"),
-               "-DNAPI_VERSION=6", "-DNODE_GYP_MODULE_NAME=headtrackr_hip", src, "-o", ADDON, "-L", HERE, "-lheadtrackr_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,--no-as-needed"]
+               "-DNAPI_VERSION=7", "-DNODE_GYP_MODULE_NAME=headtrackr_hip", src, "-o", ADDON, "-L", HERE, "-lheadtrackr_hip", "-Wl,-rpath,$ORIGIN/..", "-Wl,--no-as-needed"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -16,6 +16,11 @@
 
 static thread_local std::string g_create_err;
 
+// every live context of the process: ht_device_free looks for OTHER contexts that still have frames bound inside the buffer
+#include <mutex>
+static std::mutex g_live_mu;
+static std::vector<ht_ctx *> g_live;
+
 ht_status ht_fail(ht_ctx *ctx, ht_status st, const std::string &msg) {
     if (ctx)
         ctx->err = msg;
@@ -321,6 +326,10 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         c->err = "hipMalloc(hits) failed";
         return bail(HT_ERR_NOMEM);
     }
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.push_back(c);
+    }
     *out = c;
     return HT_OK;
 }
@@ -349,6 +358,10 @@ static void free_geometry(ht_ctx *c) {
 
 extern "C" void ht_destroy(ht_ctx *c) {
     if (!c) return;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux_stream) (void)hipStreamSynchronize(c->aux_stream), (void)hipStreamDestroy(c->aux_stream);
@@ -840,7 +853,17 @@ extern "C" ht_status ht_device_free(ht_ctx *c, void *p) {
     auto it = std::find_if(c->user_allocs.begin(), c->user_allocs.end(), [p](const std::pair<void *, size_t> &a) { return a.first == p; });
     if (it == c->user_allocs.end()) return ht_fail(c, HT_ERR_INVALID, "ht_device_free: not a live ht_device_alloc buffer of this context");
     const uint8_t *pb = static_cast<const uint8_t *>(p);
-    if (c->d_frames && c->d_frames >= pb && c->d_frames < pb + it->second) c->d_frames = nullptr, c->nframes = 0;  // frames bound inside it
+    {   // a buffer that other contexts of this device have bound (ht_bind_frames_device: a batch host shares one frame buffer between
+        // its pipelined contexts) is NOT freed under them: their next enqueue would read freed HBM.  Rebind or destroy them first.
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (ht_ctx *o : g_live)
+            if (o != c && o->device == c->device && o->d_frames && o->d_frames >= pb && o->d_frames < pb + it->second)
+                return ht_fail(c, HT_ERR_STATE, "ht_device_free: another live context still has frames bound inside this buffer (rebind or destroy it first)");
+    }
+    if (c->d_frames && c->d_frames >= pb && c->d_frames < pb + it->second) {  // frames bound inside it
+        c->d_frames = nullptr, c->nframes = 0;
+        destroy_graphs(c);  // their keys hold the freed pointer: an allocation that reuses the address must not replay them
+    }
     c->user_allocs.erase(it);
     HT_HIP(c, hipFree(p));
     return HT_OK;

@@ -68,6 +68,7 @@ napi_value throw_ht(napi_env env, ht_ctx *ctx, ht_status st, const char *where) 
 struct Slot {
     ht_ctx *ctx = nullptr;
     std::recursive_mutex mu;
+    napi_env env = nullptr;  // the environment (main thread or a worker_threads Worker) that created the context: its cleanup hook destroys it
 };
 
 bool get_slot(napi_env env, napi_value v, Slot **out) {
@@ -130,17 +131,23 @@ bool get_bytes(napi_env env, napi_value v, uint8_t **data, size_t *len) {
 // destructors crashes the process at exit.
 std::mutex g_slots_mu;
 std::vector<Slot *> g_slots;
-bool g_env_down = false;
 
-void env_cleanup(void *) {
+// Cleanup hook of ONE environment (arg = its napi_env): a Worker that exits destroys the contexts IT created, not the main thread's.
+// arg == nullptr (exitNow: the whole process is leaving): every environment's contexts.
+void env_cleanup(void *arg) {
     std::lock_guard<std::mutex> lk(g_slots_mu);
-    g_env_down = true;
     for (Slot *s : g_slots) {
+        if (arg && s->env != static_cast<napi_env>(arg)) continue;
         std::lock_guard<std::recursive_mutex> l2(s->mu);
         if (s->ctx) ht_destroy(s->ctx);
         s->ctx = nullptr;
     }
 }
+
+// hostAlloc registry: hostFree releases exactly the pointers hostAlloc returned, once (a subarray, a second view or a foreign
+// Uint8Array must never reach hipHostFree), and detaches the ArrayBuffer so that JS cannot touch the unmapped pages afterwards
+std::mutex g_host_mu;
+std::vector<std::pair<void *, size_t>> g_host_allocs;
 
 // NO finalizers on the handles this addon hands to JavaScript.  Node 12 runs finalizers that are still pending while it tears the
 // environment down, through N-API's own phantom-callback wrapper, and that wrapper crashes inside libnode (SIGSEGV at exit in
@@ -198,6 +205,7 @@ napi_value CreateContext(napi_env env, napi_callback_info info) {
     if (st != HT_OK) return throw_ht(env, nullptr, st, "ht_create");
     Slot *slot = new Slot();
     slot->ctx = ctx;
+    slot->env = env;
     {
         std::lock_guard<std::mutex> lk(g_slots_mu);
         g_slots.push_back(slot);
@@ -638,6 +646,10 @@ napi_value HostAlloc(napi_env env, napi_callback_info info) {
         return nullptr;
     }
     NAPI_OK(napi_create_typedarray(env, napi_uint8_array, (size_t)bytes, ab, 0, &ta));
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        g_host_allocs.emplace_back(p, (size_t)bytes);
+    }
     return ta;
 }
 
@@ -663,13 +675,29 @@ napi_value HostFree(napi_env env, napi_callback_info info) {
     size_t argc = 1;
     napi_value argv[1];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
-    uint8_t *p = nullptr;
-    size_t len = 0;
-    if (argc < 1 || !get_bytes(env, argv[0], &p, &len) || !p) {
+    napi_typedarray_type t;
+    size_t len = 0, off = 0;
+    void *p = nullptr;
+    napi_value ab;
+    bool is_ta = false;
+    if (argc < 1 || napi_is_typedarray(env, argv[0], &is_ta) != napi_ok || !is_ta || napi_get_typedarray_info(env, argv[0], &t, &len, &p, &ab, &off) != napi_ok || !p) {
         napi_throw_type_error(env, nullptr, "hostFree(Uint8Array returned by hostAlloc)");
         return nullptr;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        auto it = g_host_allocs.end();
+        if (off == 0)
+            for (auto i = g_host_allocs.begin(); i != g_host_allocs.end(); ++i)
+                if (i->first == p && i->second == len) it = i;
+        if (it == g_host_allocs.end()) {  // a subarray / second view / foreign array / already freed: nothing is released
+            napi_throw_error(env, nullptr, "hostFree: not a live hostAlloc() array (pass the array hostAlloc returned, whole, once)");
+            return nullptr;
+        }
+        g_host_allocs.erase(it);
+    }
     ht_host_free(p);
+    (void)napi_detach_arraybuffer(env, ab);  // every view now has length 0: no use-after-free from JavaScript
     return nullptr;
 }
 
@@ -720,8 +748,8 @@ napi_value DeviceFree(napi_env env, napi_callback_info info) {
     DevBuf *d = nullptr;
     if (argc < 2 || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
     ht_status st = ht_device_free(L.ctx, d->ptr);
+    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_device_free");  // e.g. the wrong context, or still bound elsewhere: the handle stays valid
     d->ptr = nullptr;
-    if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_device_free");
     return nullptr;
 }
 
@@ -1042,7 +1070,7 @@ napi_value FramesEnqueued(napi_env env, napi_callback_info info) { return ctx_co
 napi_value GraphLaunches(napi_env env, napi_callback_info info) { return ctx_counter(env, info, 2); }
 
 napi_value Init(napi_env env, napi_value exports) {
-    napi_add_env_cleanup_hook(env, env_cleanup, nullptr);
+    napi_add_env_cleanup_hook(env, env_cleanup, env);
     struct {
         const char *name;
         napi_callback fn;

@@ -63,10 +63,11 @@ def pack_best_records(best: np.ndarray, first_frame: int, rows: int | None = Non
     return rec
 
 
-def allgather_records(rec_local, world: int, max_frames_per_rank: int, out=None):
+def allgather_records(rec_local, world: int, max_frames_per_rank: int, out=None, force_collective: bool = False):
     """All-gathers one [max_frames_per_rank, 8] float64 tensor per rank into [world, max_frames_per_rank, 8].
     rec_local must already be padded to max_frames_per_rank rows and live on the device the backend expects.
-    out: optional preallocated result tensor (a steady-state caller reuses one per batch in flight)."""
+    out: optional preallocated result tensor (a steady-state caller reuses one per batch in flight).
+    force_collective: with one rank, still issue the collective on the initialised process group (measures the exchange step's cost on one GPU)."""
     import torch
     import torch.distributed as dist
 
@@ -74,7 +75,7 @@ def allgather_records(rec_local, world: int, max_frames_per_rank: int, out=None)
     if out is None:
         out = torch.empty((world, max_frames_per_rank, RECORD_F64), dtype=torch.float64, device=rec_local.device)
     assert out.shape == (world, max_frames_per_rank, RECORD_F64) and out.dtype == torch.float64
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):  # force_collective: a 1-rank group still goes through the backend
         out[0].copy_(rec_local)
         return out
     dist.all_gather_into_tensor(out.view(world * max_frames_per_rank, RECORD_F64), rec_local.contiguous())

@@ -111,6 +111,12 @@ function bindFrame(c, img, cascade, interval) {
   addon().upload(c.handle, img.data, 1, img.width, img.height);
   c.boundImg = img;
 }
+/* The marker lives for ONE public call: a host canvas may hand out the same ImageData object again with refreshed pixels (zero-copy
+ * video wrappers do), so object identity says nothing across calls — every public entry point that used bindFrame drops it on return. */
+function unbindFrames() {
+  const per = contexts.get(headtrackr.cascade);
+  if (per) per.forEach(function (c) { c.boundImg = null; });
+}
 headtrackr.hostAlloc = function (bytes) { return addon().hostAlloc(bytes); }; /* Uint8Array over pinned host memory */
 /* leave the process NOW: live contexts are destroyed, stdout / stderr flushed, then _exit(code) — no runtime teardown (see ht_napi.cc) */
 headtrackr.exitNow = function (code) { addon().exitNow(code | 0); };
@@ -340,6 +346,7 @@ headtrackr.ccv.detect_objects_batch = function (frames, n, w, h, cascade, interv
  *                                           last batch, hits, batches}; neighbors 0 / confidence -10000 = no face (facetrackr.js:239)
  *     detect(min_neighbors, set)           -> Array<Array<rect>>: exactly ccv.detect_objects' result per frame (parity path)
  *     whitebalance(set)                    -> Float64Array(n): getWhitebalance per frame, fused into a detect batch's gray pass
+ *     detectStep(set) / trackStep(set) / ingest(pinned) / swap()   K frame-synchronous live feeds, one time step per call (below)
  *     initTrackers(rects, set) / trackSequence(sets[], calcAngles, outAll) -> Float64Array(9 n [* calls]): n camshift streams,
  *                                           one track() per listed frame set, ONE host call (ht_camshift_track_sequence)
  *     destroy() */
@@ -365,6 +372,7 @@ headtrackr.ccv.DeviceBatch = function (w, h, n, opts) {
     A.deviceUpload(ctxs[0], dev, (set || 0) * setBytes, frames.subarray(0, setBytes));
   };
   this.detectBest = function (batches, min_neighbors, set, flags) {
+    if (!(batches >= 1)) throw new RangeError('DeviceBatch.detectBest: batches must be >= 1');
     bind(set || 0);
     flags = flags === undefined ? A.INPUT_RGBA : flags;
     min_neighbors = min_neighbors === undefined ? 1 : min_neighbors;
@@ -402,8 +410,39 @@ headtrackr.ccv.DeviceBatch = function (w, h, n, opts) {
     for (let k = 0; k < setList.length; k++) offs[k] = setList[k] * setBytes;
     return A.camshiftTrackSequence(ctxs[0], 0, n, calcAngles ? 1 : 0, dev, offs, fbytes, !!outAll, true);
   };
+  /* K frame-synchronous feeds, one time step at a time (the K-feed form of the reference's loop, main.js:168-180 -> facetrackr.js:97-108,
+   * 185-217): the n frames of `set` are the feeds' frames of this step.
+   *   detectStep(set, min_neighbors) -> Float64Array(6 n) best face per feed (as detectBest) — and camshift.initTracker on its floor()ed
+   *                                     rect (facetrackr.js:101-106); a feed without a face gets the centre half of the frame
+   *   trackStep(set, calcAngles)     -> Float64Array(9 n): camshift.track per feed (enqueue-only launch + collect) */
+  /*   ingest(pinned) / swap()        live ingest: the NEXT step's n frames cross PCIe from a hostAlloc() view on the copy stream while the
+   *                                  current step is processed (ht_upload_frames_async / ht_swap_frames); after swap() pass set = -1 */
+  const bind0 = function (set) { if (set >= 0) A.bindDevice(ctxs[0], dev, set * setBytes, n, fbytes); bound = -1; };
+  this.ingest = function (pinned) { A.uploadAsync(ctxs[0], pinned, n); };
+  this.swap = function () { A.swapFrames(ctxs[0]); bound = -1; };
+  this.detectStep = function (set, min_neighbors) {
+    bind0(set === undefined ? 0 : set);
+    A.detectEnqueue(ctxs[0], A.INPUT_RGBA);
+    const r = A.collectBest(ctxs[0], min_neighbors === undefined ? 1 : min_neighbors, -1);
+    const rects = new Int32Array(4 * n);
+    for (let f = 0; f < n; f++) {
+      const ok = r.best[6 * f + 5] > 0 && r.best[6 * f + 4] > -10;
+      const v = ok ? [r.best[6 * f], r.best[6 * f + 1], r.best[6 * f + 2], r.best[6 * f + 3]] : [w >> 2, h >> 2, w >> 1, h >> 1];
+      for (let k = 0; k < 4; k++) rects[4 * f + k] = Math.floor(v[k]);
+    }
+    if (!trackers) { A.camshiftReserve(ctxs[0], n); trackers = true; }
+    A.camshiftInitBound(ctxs[0], n, 0, rects);
+    r.rects = rects;
+    return r;
+  };
+  this.trackStep = function (set, calcAngles) {
+    bind0(set === undefined ? 0 : set);
+    A.camshiftTrackBound(ctxs[0], n, 0, calcAngles === false ? 0 : 1, false);
+    return A.camshiftTrackCollect(ctxs[0], n);
+  };
   this.graphLaunches = function () { return ctxs.reduce(function (s, c) { return s + A.graphLaunches(c); }, 0); };
-  this.destroy = function () { A.deviceFree(ctxs[0], dev); ctxs.forEach(function (c) { A.destroy(c); }); ctxs.length = 0; };
+  /* the frame buffer is shared by all `depth` contexts: the others go first (ht_device_free refuses while they have it bound) */
+  this.destroy = function () { for (let i = ctxs.length - 1; i >= 1; i--) A.destroy(ctxs[i]); A.deviceFree(ctxs[0], dev); A.destroy(ctxs[0]); ctxs.length = 0; };
 };
 
 /* ---- whitebalance ----------------------------------------------------------------------------------------------------- */
@@ -507,11 +546,11 @@ headtrackr.camshift.Tracker = function (params) { /* camshift.js:148-354 */
 
   this.initTracker = function (canvas, trackedArea) { /* camshift.js:198-211 */
     const ctx2d = canvas.getContext('2d');
-    this._initImg(ctx2d.getImageData(0, 0, canvas.width, canvas.height), trackedArea, ctx2d);
+    try { this._initImg(ctx2d.getImageData(0, 0, canvas.width, canvas.height), trackedArea, ctx2d); } finally { unbindFrames(); }
   };
 
   this.track = function (canvas) { /* camshift.js:213-259 */
-    this._trackImg(canvas.getContext('2d').getImageData(0, 0, canvas.width, canvas.height));
+    try { this._trackImg(canvas.getContext('2d').getImageData(0, 0, canvas.width, canvas.height)); } finally { unbindFrames(); }
   };
 
   /* debug getters: the back-projection is never materialised on the device (only these two functions can observe it),
@@ -643,19 +682,21 @@ headtrackr.facetrackr.Tracker = function (params) { /* facetrackr.js:37-228 */
     const ctx2d = input.getContext('2d');
     const img = ctx2d.getImageData(0, 0, input.width, input.height);
     let result;
-    if (state === 'WB') result = checkWB(img);
-    else if (state === 'VJ') result = detectVJ(img);
-    else result = detectCS(img);
+    try {
+      if (state === 'WB') result = checkWB(img);
+      else if (state === 'VJ') result = detectVJ(img);
+      else result = detectCS(img);
+      if (result.detection === 'VJ' && result.confidence > confidenceThreshold) { /* facetrackr.js:97-108 */
+        state = 'CS';
+        cs._initImg(img, new headtrackr.camshift.Rectangle(Math.floor(result.x), Math.floor(result.y),
+          Math.floor(result.width), Math.floor(result.height)), ctx2d);
+      }
+    } finally { unbindFrames(); } /* the uploaded copy is shared within this call only */
 
     if (result.detection === 'WB') { /* facetrackr.js:79-95 */
       if (wbWindow.length >= wbLength) wbWindow.pop();
       wbWindow.unshift(result.wb);
       if (wbWindow.length === wbLength && Math.max.apply(null, wbWindow) - Math.min.apply(null, wbWindow) < 2) state = 'VJ';
-    }
-    if (result.detection === 'VJ' && result.confidence > confidenceThreshold) { /* facetrackr.js:97-108 */
-      state = 'CS';
-      cs._initImg(img, new headtrackr.camshift.Rectangle(Math.floor(result.x), Math.floor(result.y),
-        Math.floor(result.width), Math.floor(result.height)), ctx2d);
     }
     current = result;
     if (result.detection === 'CS' && params.sendEvents) { /* facetrackr.js:112-125 */

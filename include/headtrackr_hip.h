@@ -163,6 +163,8 @@ int32_t ht_frames_enqueued(const ht_ctx *ctx);
 ht_status ht_host_alloc(size_t bytes, void **out);
 void ht_host_free(void *p);
 ht_status ht_device_alloc(ht_ctx *ctx, size_t bytes, void **out);
+/* Frees a buffer of ht_device_alloc on the context that allocated it.  Fails with HT_ERR_STATE (nothing freed) while ANOTHER live
+ * context still has frames bound inside it (ht_bind_frames_device): rebind or destroy that context first. */
 ht_status ht_device_free(ht_ctx *ctx, void *p);
 ht_status ht_device_upload(ht_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 

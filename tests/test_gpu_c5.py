@@ -130,3 +130,52 @@ def test_graph_replay_equals_plain_enqueue(cascade, wb, w, h, n):
     finally:
         plain.close()
         c.close()
+
+
+def test_c5_shape_from_the_node_host(cascade, tmp_path):
+    """The same 61-step cycle driven from JavaScript (tests/js/c5_stream.js: ccv.DeviceBatch.detectStep / trackStep through the N-API
+    addon): every best face bit-exact, the floored initTracker rects equal, every track object vs the oracle (sizes equal, +-1 px, counted
+    exact), and the detect sequence was replayed from its graph."""
+    import json
+    import os
+    import shutil
+    import subprocess
+
+    from conftest import ROOT
+
+    node = shutil.which("node")
+    if node is None or not os.path.exists(os.path.join(ROOT, "headtrackr_amd", "js", "headtrackr_hip.node")):
+        pytest.skip("node or the addon is missing")
+    K, steps = 8, 61
+    uniq = synth.stream_feed_frames(NUNIQ, W, H, 0)
+    raw, outf = tmp_path / "uniq.raw", tmp_path / "out.json"
+    uniq.tofile(str(raw))
+    r = subprocess.run([node, os.path.join(ROOT, "tests", "js", "c5_stream.js"), "parity", str(raw), str(NUNIQ), str(K), str(steps), str(outf)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    os.unlink(str(raw))
+    got = json.loads(outf.read_text())
+    assert got["graph_launches"] >= 2 and len(got["steps"]) == steps
+    want_best, oracles, stats = {}, [None] * K, []
+    for i, s in enumerate(got["steps"]):
+        assert s["step"] == i
+        if i % 30 == 0:
+            best = np.array(s["best"]).reshape(K, 6)
+            for f in range(K):
+                u = synth.stream_frame_index(i, f, NUNIQ)
+                if u not in want_best:
+                    want_best[u] = ho.best_faces(uniq[u : u + 1], cascade.blob, 1)[0]
+                wb = want_best[u]
+                assert list(best[f]) == [wb["x"], wb["y"], wb["width"], wb["height"], wb["confidence"], float(wb["neighbors"])], (i, f)
+                rect = tuple(int(math.floor(v)) for v in best[f][:4])
+                assert tuple(s["rects"][4 * f : 4 * f + 4]) == rect
+                oracles[f] = ho.Camshift(True)
+                oracles[f].init_tracker(uniq[u], rect)
+        else:
+            t = np.array(s["track"]).reshape(K, 9)
+            for f in range(K):
+                sw, to = oracles[f].track(uniq[synth.stream_frame_index(i, f, NUNIQ)])
+                g = dict(x=t[f][0], y=t[f][1], width=t[f][2], height=t[f][3], angle=t[f][4], sw_x=t[f][5], sw_y=t[f][6], sw_width=t[f][7], sw_height=t[f][8])
+                cs_check(g, sw, to, stats, where=("c5-node", f, i))
+    assert len(stats) == K * (steps - 3)
+    cs_all_exact(stats, "C5 shape from Node, 8 x 1080p feeds")

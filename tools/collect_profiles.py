@@ -15,13 +15,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
-short = {"k_gray_linear": "gray", "k_resample": "resample", "k_resample_tail": "resample_tail", "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep",
-         "k_scan_deep_lds": "scan_deep", "k_cs_track_fused": "cs_track", "k_cs_hist": "cs_hist", "k_cs_meanshift": "cs_meanshift", "k_cs_init": "cs_init"}
-traffic = {"_note": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/gpu_pmc.sh): bytes = "
-           "(2*FETCH_SIZE + WRITE_SIZE)*1024.  On gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section); "
-           "calibrated here on k_gray_linear, whose traffic is known exactly (reads W*H*4, writes W*H per frame): see gray_check. "
-           "Averages per launch; k_resample is the mean over its launches per step (one per pyramid generation; the last generations are one k_resample_tail launch)."}
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+# timer name (HtProfScope) of every kernel = the keys of bench.py's kernel_ms_per_step
+timer = {"k_gray_linear": "gray", "k_gray_rows": "gray", "k_resample": "resample", "k_resample_tail": "resample", "k_resample_tail_f64": "resample", "k_pyramid_frame": "resample",
+         "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep", "k_scan_deep_lds": "scan_deep", "k_cs_track_fused": "cs_track", "k_cs_hist": "cs_hist",
+         "k_cs_meanshift": "cs_meanshift", "k_cs_meanshift_cluster": "cs_meanshift", "k_cs_lut": "cs_lut", "k_cs_init": "cs_init", "k_cs_init_rows": "cs_init"}
+traffic = {"_note": "HBM bytes from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/gpu_pmc.sh): bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.  "
+           "On gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section); calibrated on k_gray_linear, whose traffic is known exactly "
+           "(reads W*H*4, writes W*H per frame): gray_check.  per_step: bytes per detect step and bench timer name = every launch's OWN counters summed over the "
+           "launches the timer covers (resample = the k_resample launches + the tail kernel); per_launch: mean per launch and kernel."}
 for wl in ("c2", "c4", "c3"):
     ks = glob.glob(os.path.join(G, f"prof_{wl}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:
@@ -49,12 +51,16 @@ for wl in ("c2", "c4", "c3"):
             fh.write("kernel,launches,counter,value_per_launch\n")
             for r in rows_out:
                 fh.write(",".join(map(str, r)) + "\n")
-    t = {}
+    launches = {r[0]: r[1] for r in rows_out}
+    steps = launches.get("k_gray_linear") or launches.get("k_gray_rows") or 0
+    pl, ps = {}, collections.defaultdict(float)
     for k, v in per.items():
-        if "FETCH_SIZE" in v and "WRITE_SIZE" in v and k in short:
-            t[short[k]] = round((2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024)
-    if t:
-        traffic[wl] = t
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v and k in timer and steps:
+            b = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
+            pl[k] = round(b)
+            ps[timer[k]] += b * launches[k] / steps
+    if ps:
+        traffic[wl] = {"per_step": {k: round(v) for k, v in ps.items()}, "per_launch": pl}
 for name in ("tile_timeline_c2.txt", "tile_timeline_c4.txt", "rs_phases_c2.txt", "rs_phases_c4.txt"):  # shader-clock phase timelines (tools/gpu_tile_timeline.py, gpu_rs_phases.py)
     src = os.path.join(G, name)
     if os.path.exists(src):
@@ -69,6 +75,6 @@ for name in ("default", "driver", "c5"):
         shutil.copy(bj, os.path.join(P, f"{tag}_bench_{name}.json"))
 if len(traffic) > 1:
     nf = {"c2": (256, 320, 240), "c4": (128, 1280, 720), "c3": (256, 320, 240)}
-    traffic["gray_check"] = {wl: {"measured": traffic[wl].get("gray"), "known": nf[wl][0] * nf[wl][1] * nf[wl][2] * 5} for wl in traffic if wl in nf}
+    traffic["gray_check"] = {wl: {"measured": traffic[wl]["per_step"].get("gray"), "known": nf[wl][0] * nf[wl][1] * nf[wl][2] * 5} for wl in traffic if wl in nf}
     json.dump(traffic, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 print(sorted(os.listdir(P)))

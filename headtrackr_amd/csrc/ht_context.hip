@@ -13,6 +13,7 @@
 #include <new>
 
 #include "ht_internal.h"
+#include "ht_hostpost.h"
 
 static thread_local std::string g_create_err;
 
@@ -20,6 +21,18 @@ static thread_local std::string g_create_err;
 #include <mutex>
 static std::mutex g_live_mu;
 static std::vector<ht_ctx *> g_live;
+
+static inline HtPostCfg post_cfg(const ht_ctx *c) { return HtPostCfg{c->interval, c->cw, c->ch}; }
+
+// workers for a batch of `frames` frames holding `hits` raw hits: option host_threads, or (auto) up to 7 when the batch is worth it
+static int ht_host_workers(const ht_ctx *c, int frames, uint32_t hits) {
+    if (c->host_threads == 0) return 0;
+    if (c->host_threads > 0) return c->host_threads;
+    if (frames < 32 || hits < 256) return 0;  // a live feed's frame or two: the hand-off would cost more than the work
+    static const int hw = (int)std::thread::hardware_concurrency();
+    return std::max(0, std::min(7, hw / 2 - 1));
+}
+
 
 ht_status ht_fail(ht_ctx *ctx, ht_status st, const std::string &msg) {
     if (ctx)
@@ -321,8 +334,8 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
     if ((st = ht_scan_pack_deep(c)) != HT_OK) return bail(st);
     if (hipHostMalloc(reinterpret_cast<void **>(&c->h_pinned), sizeof(HtCounters) + (size_t)HT_PINNED_HITS * sizeof(ht_hit), hipHostMallocDefault) != hipSuccess ||
         hipMalloc(&c->d_stats, sizeof(unsigned long long) * 64 * HT_STAT_SHARDS) != hipSuccess ||
-        hipMalloc(&c->d_counters, sizeof(HtCounters)) != hipSuccess ||
-        hipMalloc(&c->d_hits, (size_t)c->hit_capacity * sizeof(ht_hit)) != hipSuccess) {
+        // counters and hits in ONE allocation, counters first: ht_detect_collect fetches both with a single copy
+        hipMalloc(reinterpret_cast<void **>(&c->d_counters), sizeof(HtCounters) + (size_t)c->hit_capacity * sizeof(ht_hit)) != hipSuccess) {
         c->err = "hipMalloc(hits) failed";
         return bail(HT_ERR_NOMEM);
     }
@@ -330,6 +343,7 @@ extern "C" ht_status ht_create(const ht_config *cfg, const void *cascade_blob, s
         std::lock_guard<std::mutex> lk(g_live_mu);
         g_live.push_back(c);
     }
+    c->d_hits = reinterpret_cast<ht_hit *>(reinterpret_cast<uint8_t *>(c->d_counters) + sizeof(HtCounters));
     *out = c;
     return HT_OK;
 }
@@ -378,8 +392,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->ev_copy_done) (void)hipEventDestroy(c->ev_copy_done);
     if (c->ev_front_free) (void)hipEventDestroy(c->ev_front_free);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->d_hits) (void)hipFree(c->d_hits);
-    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_counters) (void)hipFree(c->d_counters);  // (d_hits lives in the same allocation)
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -404,19 +417,6 @@ extern "C" void ht_destroy(ht_ctx *c) {
 // ---------------------------------------------------------------------------------------------------------
 // geometry, ccv.js:110-147
 
-// V8's Math.pow(Math.pow(2, 1/6), i) for i = 0..5: glibc's pow() is one ulp off for i = 4, and Math.floor(W / pow)
-// (ccv.js:119-120) must see the same divisor the JavaScript reference saw.
-static const uint64_t kV8Scale6Pow[6] = {0x3ff0000000000000ULL, 0x3ff1f59ac3c7d6c0ULL, 0x3ff428a2f98d728bULL,
-                                         0x3ff6a09e667f3bcdULL, 0x3ff965fea53d6e3eULL, 0x3ffc823e074ec12bULL};
-static double bits2d(uint64_t u) {
-    double d;
-    std::memcpy(&d, &u, 8);
-    return d;
-}
-static double ht_scale_of(int interval) { return interval == 5 ? bits2d(kV8Scale6Pow[1]) : std::pow(2.0, 1.0 / (interval + 1)); }
-static double ht_scale_pow(int interval, int i) {
-    return (interval == 5 && i >= 0 && i <= 5) ? bits2d(kV8Scale6Pow[i]) : std::pow(ht_scale_of(interval), (double)i);
-}
 
 static inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
 
@@ -1014,9 +1014,11 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
     // counters + the first HT_PINNED_HITS hits in one go (pinned host memory), one synchronisation per batch
     // (speculative: as many hits as a batch of this size usually has — 64 per frame, at least 256 —, not the whole staging buffer:
     // a live feed's single frame would otherwise wait for a 196 KB copy it almost never needs; the rare excess is fetched below)
-    const uint32_t spec = std::min<uint32_t>(std::min<uint32_t>(HT_PINNED_HITS, c->hit_capacity), std::max<uint32_t>(256u, 64u * (uint32_t)std::max(c->enq_nframes, 1)));
-    HT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_counters, sizeof(HtCounters), hipMemcpyDeviceToHost, c->stream));
-    HT_HIP(c, hipMemcpyAsync(c->h_pinned + sizeof(HtCounters), c->d_hits, (size_t)spec * sizeof(ht_hit), hipMemcpyDeviceToHost, c->stream));
+    // ... and, once a batch of this context has been collected, 1.5 x what that one had: a 256-frame C2 batch has ~1.4 k hits, not 16 k)
+    uint32_t spec = std::max<uint32_t>(256u, 64u * (uint32_t)std::max(c->enq_nframes, 1));
+    if (c->spec_hint) spec = std::min(spec, std::max<uint32_t>(256u, c->spec_hint + c->spec_hint / 2 + 64u));
+    spec = std::min<uint32_t>(spec, std::min<uint32_t>(HT_PINNED_HITS, c->hit_capacity));
+    HT_HIP(c, hipMemcpyAsync(c->h_pinned, c->d_counters, sizeof(HtCounters) + (size_t)spec * sizeof(ht_hit), hipMemcpyDeviceToHost, c->stream));  // one copy: they are contiguous
     // the whitebalance sums of THIS batch travel with its counters: a re-enqueue below (or any later enqueue) zeroes and refills the
     // device sums, ht_detect_whitebalance reports the snapshot of the batch collected last
     const bool wb_snap = c->wb_enqueued && c->h_wb_pinned;
@@ -1039,6 +1041,7 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
             for (int j = 0; j < 64; j++) c->h_stage_in[j] += sh[(size_t)r * 64 + j];
     }
     const uint32_t found = c->h_counters.nhits;
+    c->spec_hint = found;
     if (total) *total = found;
     const uint32_t nfr = (uint32_t)c->enq_nframes;
     if (counts) std::memset(counts, 0, sizeof(uint32_t) * (size_t)nfr);
@@ -1071,22 +1074,21 @@ extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, ui
     }
     bool bucketed = found > 0 && nfr > 0;
     if (bucketed) {
-        std::vector<uint32_t> &start = c->h_frame_start;
-        start.assign((size_t)nfr + 1, 0u);
-        for (uint32_t i = 0; i < found && bucketed; i++) {
-            if (tmp[i].frame < nfr) start[tmp[i].frame + 1]++;
-            else bucketed = false;  // a frame index outside the batch (never produced by the kernels): plain sort below
-        }
+        // emission order (frame, scale, q, y, x).  The frame is the major key and a frame has few hits: a counting sort by frame straight
+        // into the destination, then each frame's handful ordered by one packed 48-bit key (ht_hostpost.h) — a 256-frame batch's 1.4 k
+        // hits took ~0.1 ms of the host's 0.25 ms per batch in one std::sort with the five-field comparator (profiles/r03_host_post.txt)
+        bucketed = ht_post_bucket_by_frame(tmp.data(), found, nfr, dst, c->h_frame_start, counts);
         if (bucketed) {
-            if (counts) std::memcpy(counts, start.data() + 1, sizeof(uint32_t) * (size_t)nfr);
-            for (uint32_t f = 0; f < nfr; f++) start[f + 1] += start[f];
-            for (uint32_t i = 0; i < found; i++) dst[start[tmp[i].frame]++] = tmp[i];  // start[f] ends as the END of frame f
-            auto key = [](const ht_hit &h) { return ((uint64_t)h.scale << 40) | ((uint64_t)h.q << 32) | ((uint64_t)h.y << 16) | (uint64_t)h.x; };
-            uint32_t b = 0;
-            for (uint32_t f = 0; f < nfr; f++) {
-                const uint32_t e = start[f];
-                if (e - b > 1) std::sort(dst + b, dst + e, [&](const ht_hit &p, const ht_hit &q) { return key(p) < key(q); });
-                b = e;
+            const uint32_t *se = c->h_frame_start.data();
+            if (c->collect_best_follows) {
+                c->h_sort_deferred = true;  // ht_detect_collect_best orders every frame inside its own per-frame pass
+            } else {
+                auto sort_frames = [&](int f0, int f1) {
+                    for (int f = f0; f < f1; f++) ht_post_sort_frame(dst, f ? se[f - 1] : 0u, se[f]);
+                };
+                const int nw = ht_host_workers(c, (int)nfr, found);
+                if (nw > 0) HtPool::get().run((int)nfr, 16, nw, sort_frames);
+                else sort_frames(0, (int)nfr);
             }
         }
     }
@@ -1194,166 +1196,29 @@ extern "C" ht_status ht_detect_whitebalance(ht_ctx *c, double *out, int32_t n) {
 // ---------------------------------------------------------------------------------------------------------
 // host post-processing
 
-static void level_scales(const ht_ctx *c, double *sx) {
-    const double scale = ht_scale_of(c->interval);  // ccv.js:110
-    sx[0] = 1;                                      // ccv.js:150
-    for (int i = 1; i < HT_MAX_LEVELS; i++) sx[i] = sx[i - 1] * scale;  // ccv.js:244-245 (repeated multiplication)
-}
-
-static ht_status hits_to_rects_scaled(const ht_ctx *c, const double *sx, const ht_hit *hits, uint32_t n, ht_rect *out) {
-    for (uint32_t k = 0; k < n; k++) {
-        const ht_hit &h = hits[k];
-        if (h.scale >= HT_MAX_LEVELS) return HT_ERR_INVALID;
-        const double s = sx[h.scale];
-        out[k].x = (double)(h.x * 4 + (h.q & 1) * 2) * s;   // ccv.js:228
-        out[k].y = (double)(h.y * 4 + (h.q >> 1) * 2) * s;  // ccv.js:229
-        out[k].width = (double)c->cw * s;                   // ccv.js:230
-        out[k].height = (double)c->ch * s;                  // ccv.js:231
-        out[k].confidence = h.sum;                          // ccv.js:233
-        out[k].neighbors = 1;                               // ccv.js:232
-        out[k].reserved = 0;
-    }
-    return HT_OK;
-}
-
 extern "C" ht_status ht_hits_to_rects(const ht_ctx *c, const ht_hit *hits, uint32_t n, ht_rect *out) {
     if (!c || (n && (!hits || !out))) return HT_ERR_INVALID;
+    const HtPostCfg cfg = post_cfg(c);
     double sx[HT_MAX_LEVELS];
-    level_scales(c, sx);
-    return hits_to_rects_scaled(c, sx, hits, n, out);
+    ht_post_level_scales(cfg, sx);
+    return ht_post_hits_to_rects(cfg, sx, hits, n, out);
 }
 
-namespace {
-struct Node {
-    int parent, rank;
-};
-}  // namespace
-
 extern "C" ht_status ht_group_rects(const ht_rect *seq, uint32_t n, int32_t min_neighbors, ht_rect *out, uint32_t *nout) {
-    if (!nout || (n && (!seq || !out))) return HT_ERR_INVALID;
-    *nout = 0;
-    if (n == 0) return HT_OK;
-    // union-find with rank and path compression, visiting pairs in the reference's order (ccv.js:41-89).  The pair test
-    // (ccv.js:252-261) only needs per-rectangle values: the three floor() terms and the x / y intervals are formed once per
-    // rectangle, not once per ordered pair — the same doubles, compared the same way.  Scratch vectors live per thread: a batch
-    // calls this once per frame with hits.
-    thread_local std::vector<Node> node;
-    thread_local std::vector<double> w15;
-    node.assign(n, Node{-1, 0});
-    w15.resize(n);
-    for (uint32_t i = 0; i < n; i++) w15[i] = std::floor(seq[i].width * 1.5 + 0.5);
-    auto find_root = [&](int i) {
-        while (node[i].parent != -1) i = node[i].parent;
-        return i;
-    };
-    auto compress = [&](int i, int root) {
-        while (node[i].parent != -1) {
-            const int t = i;
-            i = node[i].parent;
-            node[t].parent = root;
-        }
-    };
-    for (uint32_t i = 0; i < n; i++) {
-        int root = find_root((int)i);
-        const ht_rect &r1 = seq[i];
-        const double distance = std::floor(r1.width * 0.25 + 0.5);
-        const double xh = r1.x + distance, xl = r1.x - distance, yh = r1.y + distance, yl = r1.y - distance, w1 = r1.width, w15i = w15[i];
-        for (uint32_t j = 0; j < n; j++) {
-            const ht_rect &r2 = seq[j];
-            if (!(r2.x <= xh && r2.x >= xl && r2.y <= yh && r2.y >= yl && r2.width <= w15i && w15[j] >= w1) || i == j) continue;
-            const int root2 = find_root((int)j);
-            if (root2 == root) continue;
-            if (node[root].rank > node[root2].rank) {
-                node[root2].parent = root;
-            } else {
-                node[root].parent = root2;
-                if (node[root].rank == node[root2].rank) node[root2].rank++;
-                root = root2;
-            }
-            compress((int)j, root);
-            compress((int)i, root);
-        }
-    }
-    // class ids in first-seen order (ccv.js:90-105)
-    thread_local std::vector<int> idx;
-    thread_local std::vector<ht_rect> comps, seq2;
-    idx.resize(n);
-    int ncomp = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const int r = find_root((int)i);
-        if (node[r].rank >= 0) node[r].rank = ~ncomp++;
-        idx[i] = ~node[r].rank;
-    }
-    comps.assign((size_t)ncomp, ht_rect{0, 0, 0, 0, 0, 0, 0});
-    for (uint32_t i = 0; i < n; i++) {  // ccv.js:274-289
-        ht_rect &cp = comps[idx[i]];
-        if (cp.neighbors == 0) cp.confidence = seq[i].confidence;
-        ++cp.neighbors;
-        cp.x += seq[i].x;
-        cp.y += seq[i].y;
-        cp.width += seq[i].width;
-        cp.height += seq[i].height;
-        cp.confidence = std::max(cp.confidence, seq[i].confidence);
-    }
-    seq2.clear();
-    for (int i = 0; i < ncomp; i++) {  // ccv.js:293-303
-        const int nn = comps[i].neighbors;
-        if (nn >= min_neighbors) {
-            ht_rect r;
-            r.x = (comps[i].x * 2 + nn) / (2 * nn);
-            r.y = (comps[i].y * 2 + nn) / (2 * nn);
-            r.width = (comps[i].width * 2 + nn) / (2 * nn);
-            r.height = (comps[i].height * 2 + nn) / (2 * nn);
-            r.neighbors = nn;
-            r.reserved = 0;
-            r.confidence = comps[i].confidence;
-            seq2.push_back(r);
-        }
-    }
-    uint32_t k = 0;
-    for (size_t i = 0; i < seq2.size(); i++) {  // ccv.js:307-330
-        const ht_rect &r1 = seq2[i];
-        bool keep = true;
-        for (size_t j = 0; j < seq2.size() && keep; j++) {
-            const ht_rect &r2 = seq2[j];
-            const double distance = std::floor(r2.width * 0.25 + 0.5);
-            if (i != j && r1.x >= r2.x - distance && r1.y >= r2.y - distance && r1.x + r1.width <= r2.x + r2.width + distance &&
-                r1.y + r1.height <= r2.y + r2.height + distance && (r2.neighbors > std::max(3, r1.neighbors) || r1.neighbors < 3))
-                keep = false;
-        }
-        if (keep) out[k++] = r1;
-    }
-    *nout = k;
-    return HT_OK;
+    return ht_post_group_rects(seq, n, min_neighbors, out, nout);
 }
 
 extern "C" ht_status ht_best_faces(const ht_ctx *c, const ht_hit *hits, const uint32_t *counts, int32_t nframes, int32_t min_neighbors,
                                    ht_rect *best) {
     if (!c || !counts || !best || nframes < 0) return HT_ERR_INVALID;
-    thread_local std::vector<ht_rect> seq, grouped;
+    const HtPostCfg cfg = post_cfg(c);
     double sx[HT_MAX_LEVELS];
-    level_scales(c, sx);  // once per batch, not once per frame
+    ht_post_level_scales(cfg, sx);  // once per batch, not once per frame
     size_t k = 0;
     for (int f = 0; f < nframes; f++) {
-        const uint32_t n = counts[f];
-        ht_rect r = {0, 0, 0, 0, -10000.0, 0, 0};  // facetrackr.TrackObj defaults, facetrackr.js:233-241
-        if (n) {
-            if (!hits) return HT_ERR_INVALID;
-            seq.resize(n);
-            grouped.resize(n);
-            ht_status st = hits_to_rects_scaled(c, sx, hits + k, n, seq.data());
-            if (st != HT_OK) return st;
-            uint32_t ng = n;
-            if (min_neighbors > 0) {
-                if ((st = ht_group_rects(seq.data(), n, min_neighbors, grouped.data(), &ng)) != HT_OK) return st;
-            } else {
-                grouped = seq;
-            }
-            for (uint32_t i = 0; i < ng; i++)  // facetrackr.js:157-165
-                if (i == 0 || grouped[i].confidence > r.confidence) r = grouped[i];
-        }
-        best[f] = r;
-        k += n;
+        const ht_status st = ht_post_best_face(cfg, sx, hits ? hits + k : nullptr, counts[f], min_neighbors, &best[f]);
+        if (st != HT_OK) return st;
+        k += counts[f];
     }
     return HT_OK;
 }
@@ -1366,10 +1231,18 @@ extern "C" ht_status ht_detect_collect_best(ht_ctx *c, int32_t min_neighbors, ht
     if (c->h_collect_hits.size() < (size_t)c->hit_capacity) c->h_collect_hits.resize(c->hit_capacity);
     c->h_collect_counts.resize((size_t)std::max(nfr, 1));
     uint32_t total = 0;
+    c->collect_best_follows = true;  // the hits arrive bucketed by frame; each frame's ordering happens in the per-frame pass below
+    c->h_sort_deferred = false;
     ht_status st = ht_detect_collect(c, c->h_collect_hits.data(), c->hit_capacity, c->h_collect_counts.data(), &total);
+    c->collect_best_follows = false;
     if (total_hits) *total_hits = total;
     if (st != HT_OK) return st;
-    return ht_best_faces(c, c->h_collect_hits.data(), c->h_collect_counts.data(), nfr, min_neighbors, best);
+    if (!c->h_sort_deferred) return ht_best_faces(c, c->h_collect_hits.data(), c->h_collect_counts.data(), nfr, min_neighbors, best);
+    // One pass per frame — order its hits (emission order: scale, q, y, x), seq rects, grouping, best face — dealt out to the host pool
+    // (ht_hostpost.h): frames are independent and write their own slots, byte-identical to the single-threaded order
+    // (tests/test_host_post.py runs the same code under ASan with 0 and 7 workers).  A C2 batch took 0.144 ms of one core here, more
+    // than half of the 0.25 ms the GPU needs for it (profiles/r03_host_post.txt).
+    return ht_post_frames(post_cfg(c), c->h_collect_hits.data(), c->h_frame_start.data(), nfr, min_neighbors, ht_host_workers(c, nfr, total), best);
 }
 
 extern "C" ht_status ht_detect_collect_best_requeue(ht_ctx *c, int32_t min_neighbors, ht_rect *best, uint32_t *total_hits, uint32_t next_flags) {

@@ -309,7 +309,8 @@ struct ht_ctx {
     uint32_t hit_capacity = 1u << 20, queue_capacity = 0, queue_capacity_cfg = 0;
     ht_hit *d_hits = nullptr;
     HtQueueEntry *d_queue = nullptr;
-    HtCounters *d_counters = nullptr;
+    HtCounters *d_counters = nullptr;   // device block [HtCounters][hit_capacity x ht_hit]: d_hits points behind the counters
+    uint32_t spec_hint = 0;             // raw hits of the batch collected last (sizes the next speculative read-back)
     HtCounters h_counters;
     uint8_t *h_pinned = nullptr;  // pinned staging: [HtCounters][HT_PINNED_HITS x ht_hit], one D2H + one sync per batch
     unsigned long long *d_stats = nullptr;      // [HT_STAT_SHARDS][64], only touched with HT_SCAN_STATS
@@ -321,6 +322,8 @@ struct ht_ctx {
     std::vector<uint32_t> h_frame_start;       // ... bucket offsets of the counting sort by frame
     bool stats_enqueued = false;
     bool enqueued = false;
+    bool collect_best_follows = false;  // set by ht_detect_collect_best around its ht_detect_collect: the per-frame ordering is left to its own per-frame pass
+    bool h_sort_deferred = false;       // ... and this says that it was
 
     // whitebalance / grayscale scratch
     double *d_scratch = nullptr;

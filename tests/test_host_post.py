@@ -69,3 +69,106 @@ def test_group_rects_nan_and_degenerate_widths():
         assert len(got) == len(want)
         for f in ("x", "y", "width", "height", "confidence", "neighbors"):
             assert np.array_equal(np.asarray(got[f]), np.asarray(want[f]), equal_nan=True), (mn, f)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The per-batch host pass (ht_hostpost.h: counting sort by frame, per-frame ordering, seq rects, grouping, best face, worker pool)
+# compiled with AddressSanitizer + UBSan into a host-only harness and run on seeded raw-hit sets: sanitizer-clean, equal to the oracle,
+# and byte-identical with 0, 3 and 7 workers.
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    import os
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = str(tmp_path_factory.mktemp("hostpost") / "hostpost_harness")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-pthread",
+                           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "headtrackr_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host", "hostpost_harness.cc"), "-o", exe])
+    return exe
+
+
+def _raw_hits(rng, nfr, faces_per_frame, strays):
+    """raw hits as the kernels append them: index form, frames interleaved in arrival order"""
+    rows = []
+    for f in range(nfr):
+        for _ in range(int(rng.integers(0, faces_per_frame + 1))):
+            s0, x0, y0 = int(rng.integers(0, 14)), int(rng.integers(0, 40)), int(rng.integers(0, 30))
+            for _ in range(int(rng.integers(1, 14))):
+                rows.append((f, x0 + int(rng.integers(0, 2)), y0 + int(rng.integers(0, 2)), min(26, s0 + int(rng.integers(0, 3))), int(rng.integers(0, 4)), 0, 0, float(rng.normal(3, 2))))
+        for _ in range(int(rng.integers(0, strays + 1))):
+            rows.append((f, int(rng.integers(0, 60)), int(rng.integers(0, 45)), int(rng.integers(0, 27)), int(rng.integers(0, 4)), 0, 0, float(rng.normal(0, 1))))
+    seen, uniq = set(), []
+    for r in rows:  # a window is scanned once: (frame, scale, q, y, x) is unique in a batch's raw hits
+        key = (r[0], r[3], r[4], r[2], r[1])
+        if key not in seen:
+            seen.add(key)
+            uniq.append(r)
+    a = np.array(uniq, dtype=native.HIT_DTYPE) if uniq else np.zeros(0, dtype=native.HIT_DTYPE)
+    return a[rng.permutation(len(a))] if len(a) else a
+
+
+def _run_harness(exe, tmp_path, raw, nfr, min_neighbors, workers, repeat=1):
+    import os
+    import subprocess
+
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as fh:
+        fh.write(np.array([nfr, len(raw), min_neighbors, 5], dtype=np.int32).tobytes())
+        fh.write(np.ascontiguousarray(raw).tobytes())
+    r = subprocess.run([exe, fin, fout, str(workers), str(repeat)], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    blob = open(fout, "rb").read()
+    ok = int(np.frombuffer(blob[:4], dtype=np.uint32)[0])
+    if not ok:
+        return 0, None, None, None
+    o = 4
+    hits = np.frombuffer(blob[o:o + len(raw) * 24], dtype=native.HIT_DTYPE); o += len(raw) * 24
+    counts = np.frombuffer(blob[o:o + 4 * nfr], dtype=np.uint32); o += 4 * nfr
+    best = np.frombuffer(blob[o:o + 48 * nfr], dtype=native.RECT_DTYPE)
+    return ok, hits, counts, best
+
+
+@pytest.mark.parametrize("seed,nfr,faces,strays", [(1, 256, 2, 3), (2, 64, 1, 0), (3, 300, 3, 6), (4, 1, 2, 2), (5, 40, 0, 0)])
+def test_host_pass_under_asan_equals_oracle_for_any_worker_count(harness, tmp_path, seed, nfr, faces, strays):
+    rng = np.random.default_rng(seed)
+    raw = _raw_hits(rng, nfr, faces, strays)
+    # the oracle's answer: per frame, hits in emission order (scale, q, y, x), seq rects, grouping, strict-'>' best face
+    order = np.lexsort((raw["x"], raw["y"], raw["q"], raw["scale"], raw["frame"])) if len(raw) else np.zeros(0, dtype=np.int64)
+    want_hits = raw[order]
+    want_counts = np.bincount(raw["frame"], minlength=nfr).astype(np.uint32) if len(raw) else np.zeros(nfr, dtype=np.uint32)
+    want_best = np.zeros(nfr, dtype=ho.RECT_DTYPE)
+    k = 0
+    for f in range(nfr):
+        h = want_hits[k:k + int(want_counts[f])]
+        k += int(want_counts[f])
+        oh = np.zeros(len(h), dtype=ho.HIT_DTYPE)
+        for fld in ("scale", "q", "x", "y", "sum"):
+            oh[fld] = h[fld]
+        g = ho.group(ho.hits_to_rects(oh), 1)
+        want_best[f]["confidence"] = -10000.0
+        for i in range(len(g)):
+            if i == 0 or g[i]["confidence"] > want_best[f]["confidence"]:
+                want_best[f] = g[i]
+    outs = []
+    for workers in (0, 3, 7):
+        ok, hits, counts, best = _run_harness(harness, tmp_path, raw, nfr, 1, workers, repeat=3)
+        assert ok == 1
+        assert hits.tobytes() == want_hits.tobytes() and np.array_equal(counts, want_counts)
+        for fld in ("x", "y", "width", "height", "confidence", "neighbors"):
+            assert np.array_equal(best[fld], want_best[fld]), (workers, fld)
+        outs.append(best.tobytes())
+    assert outs[0] == outs[1] == outs[2]
+
+
+def test_host_pass_rejects_a_frame_index_outside_the_batch(harness, tmp_path):
+    """the counting sort indexes its bucket table with the hit's frame: a corrupt index must be reported, never written through (ASan watches)"""
+    rng = np.random.default_rng(9)
+    raw = _raw_hits(rng, 8, 2, 2).copy()
+    raw["frame"][len(raw) // 2] = 8
+    ok, *_ = _run_harness(harness, tmp_path, raw, 8, 1, 3)
+    assert ok == 0

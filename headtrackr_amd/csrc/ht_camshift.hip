@@ -899,6 +899,7 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
 }
 
 extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n, const ht_cs_rect *rects) {
+    HtRange range("ht_camshift_init_batch");
     if (!c || !rects) return HT_ERR_INVALID;
     if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_camshift_init_batch: bind n frames first");
     if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_init_batch: stream range not reserved");
@@ -987,6 +988,7 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
 }
 
 extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n, int32_t calc_angles, ht_cs_trackobj *out) {
+    HtRange range("ht_camshift_track_batch");
     if (!c) return HT_ERR_INVALID;
     if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_batch: bind n frames first");
     if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_track_batch: stream range not reserved");
@@ -1005,6 +1007,7 @@ extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n
 }
 
 extern "C" ht_status ht_camshift_track_collect(ht_ctx *c, int32_t n, ht_cs_trackobj *out) {
+    HtRange range("ht_camshift_track_collect");
     if (!c || !out || n <= 0) return HT_ERR_INVALID;
     if (c->cs_track_pending_n != n) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_collect: no enqueue-only ht_camshift_track_batch of n streams is pending");
     HT_HIP(c, hipSetDevice(c->device));
@@ -1017,6 +1020,7 @@ extern "C" ht_status ht_camshift_track_collect(ht_ctx *c, int32_t n, ht_cs_track
 
 extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_t n, int32_t calc_angles, const void *const *dev_frames,
                                                 int32_t ncalls, size_t frame_stride, ht_cs_trackobj *out, int32_t out_all) {
+    HtRange range("ht_camshift_track_sequence");
     if (!c || !dev_frames) return HT_ERR_INVALID;
     if (c->W == 0) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_sequence: call ht_set_geometry first");
     if (n <= 0 || ncalls <= 0 || frame_stride < (size_t)c->W * c->H * 4 || (frame_stride & 3))

@@ -17,6 +17,34 @@
 
 static thread_local std::string g_create_err;
 
+// roctx (see ht_internal.h)
+#include <dlfcn.h>
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        void *h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_GLOBAL);
+        if (h) {
+            push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (!push || !pop) push = nullptr, pop = nullptr;
+        }
+    }
+};
+Roctx &roctx() {
+    static Roctx r;
+    return r;
+}
+}  // namespace
+HtRange::HtRange(const char *name) : on(roctx().push != nullptr) {
+    if (on) roctx().push(name);
+}
+HtRange::~HtRange() {
+    if (on) roctx().pop();
+}
+
 // every live context of the process: ht_device_free looks for OTHER contexts that still have frames bound inside the buffer
 #include <mutex>
 static std::mutex g_live_mu;
@@ -734,6 +762,7 @@ extern "C" ht_status ht_plane(const ht_ctx *c, int32_t level, int32_t slot, ht_p
 
 extern "C" ht_status ht_upload_frames(ht_ctx *c, const uint8_t *host_rgba, int32_t n, size_t frame_stride) {
     if (!c) return HT_ERR_INVALID;
+    HtRange range("ht_upload_frames");
     if (c->W == 0) return ht_fail(c, HT_ERR_STATE, "ht_upload_frames: call ht_set_geometry first");
     const size_t fbytes = (size_t)c->W * c->H * 4;
     if (!host_rgba || n <= 0 || n > c->max_batch || frame_stride < fbytes)
@@ -939,6 +968,7 @@ extern "C" uint64_t ht_graph_launches(const ht_ctx *c) { return c ? c->graph_lau
 
 extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
     if (!c) return HT_ERR_INVALID;
+    HtRange range("ht_detect_enqueue");
     if (!c->d_frames || c->nframes <= 0) return ht_fail(c, HT_ERR_STATE, "ht_detect_enqueue: no frames bound");
     HT_HIP(c, hipSetDevice(c->device));
     ht_status st;
@@ -1009,6 +1039,7 @@ static inline bool hit_less(const ht_hit &a, const ht_hit &b) {  // emission ord
 
 extern "C" ht_status ht_detect_collect(ht_ctx *c, ht_hit *hits, uint32_t cap, uint32_t *counts, uint32_t *total) {
     if (!c) return HT_ERR_INVALID;
+    HtRange range("ht_detect_collect");
     if (!c->enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_collect: nothing enqueued");
     HT_HIP(c, hipSetDevice(c->device));
     // counters + the first HT_PINNED_HITS hits in one go (pinned host memory), one synchronisation per batch
@@ -1225,6 +1256,7 @@ extern "C" ht_status ht_best_faces(const ht_ctx *c, const ht_hit *hits, const ui
 
 extern "C" ht_status ht_detect_collect_best(ht_ctx *c, int32_t min_neighbors, ht_rect *best, uint32_t *total_hits) {
     if (!c || !best) return HT_ERR_INVALID;
+    HtRange range("ht_detect_collect_best");
     if (!c->enqueued) return ht_fail(c, HT_ERR_STATE, "ht_detect_collect_best: nothing enqueued");
     const int nfr = c->enq_nframes;
     // the context's own buffers: nothing but the per-frame rects crosses the ABI (a batch server calls this once per batch)

@@ -375,6 +375,14 @@ struct ht_ctx {
     std::vector<HtKernelTimer> timers;
 };
 
+// roctx ranges around the host-side phases of a batch: libroctx64 is looked up once with dlopen; without it (or without a
+// profiler attached) a range costs one predictable branch.  rocprofv3 --marker-trace shows "ht_detect_enqueue", "ht_detect_collect", ...
+struct HtRange {
+    explicit HtRange(const char *name);
+    ~HtRange();
+    bool on;
+};
+
 // error helpers -------------------------------------------------------------------------------------------
 ht_status ht_fail(ht_ctx *ctx, ht_status st, const std::string &msg);
 #define HT_HIP(ctx, call)                                                                                   \

@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libheadtrackr_hip.so")
+# HEADTRACKR_HIP_LIB: load another BUILD of the same library (an instrumented variant from tools/build_alt.py) — a loader path like
+# LD_LIBRARY_PATH, not a behaviour switch: the library itself reads no environment variable
+LIB_PATH = os.environ.get("HEADTRACKR_HIP_LIB") or os.path.join(_HERE, "libheadtrackr_hip.so")
 
 HT_OK = 0
 HT_ERR_CAPACITY = -4

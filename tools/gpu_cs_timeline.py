@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""tools/gpu_cs_timeline.py — phase timeline of k_cs_track_fused from a -DHT_CS_TIMELINE build (alt/cstl.so copied over the
-library): shader-clock stamps of workgroups 0..7 for one track() call of the C3 workload.  Stamps: 0 start, 1 histogram done,
+"""tools/gpu_cs_timeline.py — phase timeline of k_cs_track_fused from a -DHT_CS_TIMELINE build (HEADTRACKR_HIP_LIB=alt/cstl.so): shader-clock stamps of workgroups 0..7 for one track() call of the C3 workload.  Stamps: 0 start, 1 histogram done,
 2 LUT done, 3 region cached, 4.. after each moment pass, last = loop done."""
 import os
 import sys
@@ -10,7 +9,6 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ["HT_DEBUG_CS_KEEP_HIST"] = "1"
 from headtrackr_amd import synth  # noqa: E402
 from headtrackr_amd.api import Context  # noqa: E402
 from hipmem import DeviceArray  # noqa: E402
@@ -25,7 +23,7 @@ for f in range(n):
         vers[v, f] = synth.face_frame(W, H, [(x, y, s0)])
         x += int(walk[2 * (f * NV + v)] % 7) - 3
         y += int(walk[2 * (f * NV + v) + 1] % 7) - 3
-c = Context()
+c = Context(options="cs_keep_hist=1")
 dev = [DeviceArray(vers[v]) for v in range(NV)]
 c.set_geometry(W, H, n)
 c.bind_device(dev[0].ptr, n)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/gpu_deep_timeline.py [c2|c4] — where k_scan_deep_lds spends its time, from a -DHT_DEEP_TIMELINE build (python tools/build_alt.py
-dltl HT_DEEP_TIMELINE; copy alt/dltl.so over the library).  Per wavefront, first window only: entry -> table copied -> patch loaded -> window
+dltl HT_DEEP_TIMELINE; run with HEADTRACKR_HIP_LIB=alt/dltl.so).  Per wavefront, first window only: entry -> table copied -> patch loaded -> window
 done, by the last stage the window ran."""
 import ctypes as C
 import os

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/gpu_rs_phases.py [c2|c4] — where a k_resample workgroup spends its life, from a -DHT_RS_PHASES build (python tools/build_alt.py
-rsph HT_RS_PHASES=1; copy alt/rsph.so over the library).  Phases: 1 record + taps + first loads issued + barrier (once per workgroup);
+rsph HT_RS_PHASES=1; run with HEADTRACKR_HIP_LIB=alt/rsph.so).  Phases: 1 record + taps + first loads issued + barrier (once per workgroup);
 per frame of the group: 2 loop top, 3 next frame's loads issued, 4 pixels, 5 stores issued + barrier (every wave done with the tile),
 6 wait for the prefetched loads + registers -> LDS + barrier."""
 import ctypes as C

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/gpu_tile_timeline.py [c2|c4] — where a k_scan_tiles workgroup spends its life, from a -DHT_TILE_TIMELINE build
-(python tools/build_alt.py tltl HT_TILE_TIMELINE; tools/gpu_final.sh copies alt/tltl.so over the library for the run).  Thread 0 of every workgroup adds the
+(python tools/build_alt.py tltl HT_TILE_TIMELINE; run with HEADTRACKR_HIP_LIB=alt/tltl.so, as tools/gpu_final.sh does).  Thread 0 of every workgroup adds the
 shader-clock time of each phase to the statistics rows; this prints mean cycles per phase over the workgroups that went
 through it, and each phase's share of all workgroup-cycles."""
 import ctypes as C

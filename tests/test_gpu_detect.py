@@ -340,3 +340,31 @@ def test_async_upload_and_swap(cascade):
         assert got.tobytes() == want_a.tobytes()
     finally:
         c.close()
+
+
+def test_options_are_per_context_and_result_changing_keys_are_rejected(cascade):
+    """ht_config.options: an unknown key, a malformed value and — in the product build — the keys that make results incomplete by design
+    (they exist only in -DHT_DEBUG_KNOBS builds) fail ht_create with HT_ERR_INVALID; a dict is accepted; an ABI-1 caller (struct without the
+    options member) still gets a context."""
+    import ctypes as C
+
+    from headtrackr_amd import native
+    from headtrackr_amd.api import HtError
+
+    for bad in ("nonsense=1", "cs_fused_min=abc", "stop_stage=3", "cs_iters=2", "rs_maxgen=1"):
+        with pytest.raises(HtError) as e:
+            Context(options=bad)
+        assert e.value.status == -1, bad
+    frames = synth.mixed_batch(3, 320, 240, seed0=1234)
+    a = Context(options={"graph_max_frames": 0, "host_threads": 3})
+    b = Context()
+    try:
+        assert a.detect_raw(frames)[0].tobytes() == b.detect_raw(frames)[0].tobytes()
+    finally:
+        a.close()
+        b.close()
+    L = native.lib()
+    cfg = native.Config(32, 0, 5, 0, None, 0, 0, None)  # ABI 1: struct_size stops before `options`
+    h = C.c_void_p()
+    assert L.ht_create(C.byref(cfg), cascade.blob, len(cascade.blob), C.byref(h)) == 0
+    L.ht_destroy(h)

@@ -246,7 +246,7 @@ struct ht_ctx {
     bool builtin_cascade = false;  // blob == the cascade ht_cascade_gen.inc was generated from
     uint32_t deep_bias = 1;        // tile kernel hands survivors to the deep kernel when n*bias*ceil(count/64) <= count
                                    // (measured on C2/C4: split 8 + bias 0..1 is the optimum, profiles/r01_sweeps.txt)
-    int dbg_stop_stage = -1, dbg_force_exact = 0, dbg_deep_v = 4, deep_grid = 512;  // ht_config.options, parsed once in ht_create
+    int dbg_stop_stage = -1, dbg_force_exact = 0, dbg_deep_v = 4, deep_grid = 192;  // ht_config.options, parsed once in ht_create
     HtDevStage *d_stages = nullptr;
     uint32_t split_stage = 4;  // stages [0, split) in the tile kernel, [split, nstages) in the deep kernel
     int opt_split = 0;         // option split (0 = default)

@@ -1364,6 +1364,12 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
                 HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_scan_deep_lds), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
                 c->deep_attr_set = true;
             }
+            // Grid: 192 workgroups (option deep_grid), not the 512 that would give every queued window of a C2 batch a wavefront of its own.
+            // A workgroup holds 77 KB of LDS for as long as its slowest window lives: 512 of them take every CU's LDS for the whole launch and
+            // nothing of the other batch in flight runs beside it; 192 leave a quarter of the CUs free and half of the LDS on the others.
+            // Measured with two batches in flight (round 4, tools/gpu_kernel_times.py): the kernel itself 0.038 -> 0.055 ms, the C2 step
+            // 0.2514 -> 0.2440 ms (96 / 128 / 160 / 192 / 224 / 256 / 320 / 384 / 512 workgroups: 0.2528 / 0.2465 / 0.2445 / 0.2439 / 0.2470 /
+            // 0.2456 / 0.2474 / 0.2480 / 0.2514), C4 unchanged; 8- and 16-wavefront workgroups have the same optimum.
             hipLaunchKernelGGL(k_scan_deep_lds, dim3((uint32_t)c->deep_grid), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                                c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, force_exact, c->d_queue, c->queue_capacity,
                                c->d_hits, c->hit_capacity, c->d_counters, stats);

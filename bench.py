@@ -65,8 +65,7 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=6.0, help="budget of each cpu_baseline leg (0 = skip)")
     ap.add_argument("--flags", type=int, default=0, help="ht_detect flags (A/B of scan schedules)")
     ap.add_argument("--pipeline", type=int, default=0, help="batches in flight (contexts on their own HIP streams); 1 = enqueue+collect strictly in turn; "
-                    "0 = auto: 2 (round 3, with the re-enqueue inside the collect call: 320x240 x 256 runs 985 k frames/s at 2 and 982 k at 3 over 1000 steps, "
-                    "and a 20-step block pays one batch less of fill: 921-944 k at 2, 889-899 k at 3; 1280x720 x 128 was best at 2 already)")
+                    "0 = auto: 3 at 320x240, 2 at 1280x720 (measured, see detect_bench)")
     ap.add_argument("--prewarm", type=float, default=0.2, help="seconds of untimed steady-state work before the warm-up steps (0 for profiler runs)")
     ap.add_argument("--no-sub", action="store_true", help="only the primary workload (no c4 / c3 sub-records)")
     ap.add_argument("--no-requeue", action="store_true", help="A/B: enqueue a context's next batch only after its results were post-processed")
@@ -270,7 +269,12 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     idx = torch.arange(nf, device="cuda") % uniq
     dev = dev_uniq[idx].contiguous() if nf != uniq else dev_uniq  # resident in HBM before the timed region
     del dev_uniq
-    depth = a.pipeline if a.pipeline > 0 else 2  # profiles/r03_pipeline_depth.txt
+    # batches in flight: 3 at 320x240, 2 at 1280x720.  Round 3 measured 2 = 3 at C2 with the deep kernel on 512 workgroups (each holding 77 KB of
+    # LDS: it shut the other batches out of every CU).  With that kernel on 192 workgroups a third batch has something to overlap with: C2
+    # 0.2449 / 0.2317 / 0.2598 ms per step at 2 / 3 / 4 in flight (1000-step blocks), 0.2489 / 0.2400 at 2 / 3 in the driver's 20-step blocks;
+    # C4 1.113 / 1.112 at 2 / 3 (a third 700 MB arena buys nothing there).  LABLOG.md round 4.
+    # c2_large (1024 frames per batch, 760 MB per context) is back at 2: 1 152 k frames/s at 2, 1 111 k at 3.
+    depth = a.pipeline if a.pipeline > 0 else (3 if nf * (4 * W * H + 440000 * (W * H) // 76800) <= 256 * 1024 * 1024 else 2)
     ctxs = []
     for _ in range(depth):
         cx = Context(device=local)
@@ -948,7 +952,7 @@ def main():
                     sk.close()
                     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
                     g = {}
-                    for nm, st_, key in (("c2", 200, None), ("c4", SUB_STEPS["c4"], "c4_1gpu")):
+                    for nm, st_, key in (("c2", a.steps, None), ("c4", SUB_STEPS["c4"], "c4_1gpu")):  # the same block lengths as the records they are compared with
                         r = detect_bench(env, a, nm, st_, 10, cpu_seconds=0, prewarm=0.1, full=False, gather=True)
                         ref = sub[key] if key else None
                         g[nm] = dict(ms_per_step=r["ms_per_step"], ms_per_step_min=r["ms_per_step_min"], ms_per_step_max=r["ms_per_step_max"], value=r["value"],

@@ -281,7 +281,7 @@ struct ht_ctx {
     int rs_maxgen = 1 << 30;         // HT_DEBUG_KNOBS builds only (results stale): pyramid generations built
     bool force_rccl = false;         // option force_rccl: ht_allgather_* runs RCCL even with one rank
     int host_threads = -1;           // option host_threads: workers of the host post-processing (-1 = auto, 0 = none)
-    int rs_min_wgs = 2048;  // ... but never fewer workgroups per launch than this (option rs_minwg)
+    int rs_min_wgs = 1536;  // ... but never fewer workgroups per launch than this (option rs_minwg; round 4, three batches in flight at C2: 1024 / 1536 / 2048 / 4096 -> 0.2288 / 0.2283 / 0.2303 / 0.2365 ms per step)
     int dbg_rs_k = 0;  // option rs_k: frames per k_resample workgroup, forced (any value)
     int rs_group = 8;  // k_resample: frames per workgroup at most (option rs_group)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)

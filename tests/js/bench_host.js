@@ -40,7 +40,7 @@ const out = { node: process.version, cpus: require('os').cpus().length, cpu_mode
       what: 'ccv.detect_objects_batch(frames, n, w, h): pageable host frames cross PCIe every call; full grouped rect lists in JS' };
   }
   {
-    const b = new headtrackr.ccv.DeviceBatch(W, H, n, { depth: +(process.env.HT_JS_DEPTH || 2) });
+    const b = new headtrackr.ccv.DeviceBatch(W, H, n, process.env.HT_JS_DEPTH ? { depth: +process.env.HT_JS_DEPTH } : {});
     b.upload(frames);
     b.detectBest(12); /* warm-up */
     let batches = 0, r = null;

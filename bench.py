@@ -451,10 +451,10 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
             x += int(walk[2 * (f * NV + v)] % 7) - 3
             y += int(walk[2 * (f * NV + v) + 1] % 7) - 3
     dev_vers = [torch.from_numpy(vers[v]).cuda() for v in range(NV)]
-    # Two contexts take the steps in turn (own HIP streams, own tracker states): while one batch of streams is in its 60 track()
-    # calls (one launch, one workgroup per stream: half of every CU idle) the next step's detect runs on the other context.
+    # Three contexts take the steps in turn (own HIP streams, own tracker states): while one batch of streams is in its 60 track()
+    # calls (one launch, one workgroup per stream: half of every CU idle) the next steps' detects run on the other contexts.
     # --pipeline 1 keeps the steps strictly in turn.
-    depth = 1 if a.pipeline == 1 else 2
+    depth = a.pipeline if a.pipeline > 0 else 3  # steps in flight, measured (round 4): 6.23 / 6.82 / 6.41 M frames/s at 2 / 3 / 4
     ctxs = []
     for _ in range(depth):
         cx = Context(device=local)

@@ -159,7 +159,8 @@ struct alignas(64) HtTileRec {
     uint32_t size;                 // tw | th << 16: half-window steps of the tile that hold windows (clipped to the scale)
     uint32_t tw2_l0;               // tile pitch tw2 (window id = Y' * tw2 + X') | the scale's level index << 16
     uint32_t div_magic;            // ceil(2^20 / tw2)
-    uint32_t pad[3];
+    uint32_t strip_magic;          // ceil(2^24 / (4 * th)): stage 0 walks the tile in strips of 4 window pairs (see k_scan_tiles)
+    uint32_t pad[2];
 };
 static_assert(sizeof(HtTileRec) == 64, "HtTileRec");
 

@@ -347,13 +347,32 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 uint32_t id[2], xx[2], yy[2], Fv[2];
                 bool valid[2];
                 if (PAIR) {
+                    // Order of the walk: window PAIRS in vertical strips of 4 pairs (8 half-steps), row by row inside a strip.  A pair's
+                    // dword reads are `base + constant` with base / 4 = 76 * Y' + X' / 2, and a wave64 ds_read_b32 is served in two
+                    // groups of 32 lanes over 32 banks: 8 consecutive rows x 4 consecutive pairs are 32 different banks (76 = 12 mod 32:
+                    // the rows start at banks 0, 12, 24, 4, 16, 28, 8, 20), so every group is conflict-free.  Walking whole rows
+                    // (pair n = row-major) put rows of tw2 / 2 < 32 pairs — all but 2 of the 19 scales at 320x240 — into groups that
+                    // wrap to the next row 12 banks on: 2 cycles instead of 1 for nearly every one of stage 0's reads
+                    // (tools/sim_scan_lds2.py: stage 0 at 1.86 LDS cycles per conflict-free cycle, 1.14 in strips; the PMC counters
+                    // had 37 % of the kernel's LDS cycles as bank conflicts).  Window ids keep their meaning (Y' * tw2 + X').
                     const uint32_t lim = min(b_hi * 64u, n_in);
-                    id[0] = bt * 64u + 2u * lane;
-                    const bool in0 = id[0] < lim;  // ids come in even / odd pairs of one row: tw2 is even
-                    id[0] = in0 ? id[0] : 0u;
+                    const uint32_t pn = bt * 32u + lane;  // pair index in walking order
+                    const bool in0 = 2u * pn < lim;
+                    const uint32_t pn0 = in0 ? pn : 0u;
+#ifndef HT_TILE_STRIPS
+#define HT_TILE_STRIPS 1
+#endif
+                    if (HT_TILE_STRIPS) {
+                        const uint32_t strip = __umul24(pn0, R.strip_magic) >> 24, rem = pn0 - __umul24(strip, 4u * (uint32_t)th);
+                        yy[0] = yy[1] = rem >> 2;
+                        xx[0] = 8u * strip + 2u * (rem & 3u);
+                        id[0] = __umul24(yy[0], (uint32_t)S.tw2) + xx[0];
+                    } else {
+                        id[0] = 2u * pn0;  // ids come in even / odd pairs of one row: tw2 is even
+                        yy[0] = yy[1] = __umul24(id[0], S.div_magic) >> 20;
+                        xx[0] = id[0] - __umul24(yy[0], (uint32_t)S.tw2);
+                    }
                     id[1] = id[0] + 1u;
-                    yy[0] = yy[1] = __umul24(id[0], S.div_magic) >> 20;
-                    xx[0] = id[0] - __umul24(yy[0], (uint32_t)S.tw2);
                     xx[1] = xx[0] + 1u;
                     valid[0] = in0 && xx[0] < (uint32_t)tw;
                     valid[1] = in0 && xx[1] < (uint32_t)tw;
@@ -1285,6 +1304,12 @@ ht_status ht_scan_plan_tiles(ht_ctx *c) {
                     r.size = (uint32_t)std::min(S.tw2, 2 * S.qw - X0) | (uint32_t)std::min(S.th2, 2 * S.qh - Y0) << 16;
                     r.tw2_l0 = (uint32_t)S.tw2 | (uint32_t)S.l0 << 16;
                     r.div_magic = S.div_magic;
+                    {  // n / (4 * th) == (n * magic) >> 24 for every pair index n of the tile (n <= 1024, 4 * th <= 128: error term n * 127 < 2^24 / 128); checked anyway
+                        const uint32_t th = r.size >> 16, d = 4u * th;
+                        r.strip_magic = ((1u << 24) + d - 1u) / d;
+                        for (uint32_t n = 0; n < (uint32_t)(S.tw2 / 2) * th; n++)
+                            if (((n * r.strip_magic) >> 24) != n / d) return ht_fail(c, HT_ERR_INVALID, "tile plan: strip_magic is not exact");
+                    }
                     recs.push_back(r);
                 }
         }

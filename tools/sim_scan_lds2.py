@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""tools/sim_scan_lds2.py — CPU model of the LDS bank conflicts of k_scan_tiles AS IT IS NOW (pair-mode stage 0 on aligned dword
+reads, wave-private queues, byte reads in the stages after it) for different orders in which stage 0 walks a tile's windows.
+
+A wave64 LDS read is serviced in two groups of 32 lanes; a group takes max over the 32 banks of the number of DISTINCT dwords asked
+of that bank (MI355X_MICROARCH.md, LDS).  All reads of a stage are `window base + constant`: for the dword reads of stage 0 a
+constant only rotates the banks, so one evaluation per group stands for all 30 reads; for the byte reads of later stages
+(base is even) the pattern depends on the constant mod 4 only.
+
+    python tools/sim_scan_lds2.py [nframes] [w h]
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from headtrackr_amd import synth  # noqa: E402
+from headtrackr_amd.cascade import load_cascade  # noqa: E402
+from oracle import ht_oracle as ho  # noqa: E402
+import sim_scan_lds as s1  # noqa: E402
+
+NST = 8
+TXH, TYH = 64, 32
+PITCH0 = 152
+ROWS0 = 2 * TYH + 22
+P12 = PITCH0 * ROWS0
+
+
+def group_cycles_dw(dw, valid):
+    """dw, valid: [G, 32] -> cycles per group (>= 1)"""
+    G = dw.shape[0]
+    cyc = np.ones(G, dtype=np.int64)
+    bank = dw & 31
+    for g in range(G):
+        v = valid[g]
+        if not v.any():
+            continue
+        key = np.unique(dw[g][v])
+        cyc[g] = np.bincount(key & 31, minlength=32).max()
+    return cyc
+
+
+def tile_shapes(W2, H2):
+    ntx = -(-W2 // TXH)
+    tw2 = (-(-W2 // ntx) + 7) & ~7
+    nty = -(-H2 // TYH)
+    th2 = -(-H2 // nty)
+    th2 += th2 & 1
+    return tw2, th2, -(-W2 // tw2), -(-H2 // th2)
+
+
+def enum_pairs(scheme, tw2, th, tw):
+    """order in which stage 0 walks the tile's window PAIRS: arrays (row, pair index, valid0, valid1) in lane order"""
+    pw = tw2 // 2
+    if scheme == "rowmajor":
+        n = np.arange(pw * th)
+        row, p = n // pw, n % pw
+    elif scheme == "strip4":
+        n = np.arange(pw * th)
+        strip, rem = n // (4 * th), n % (4 * th)
+        row, p = rem >> 2, strip * 4 + (rem & 3)
+    elif scheme == "strip12":  # strips of 12 pairs, the remainder in strips of 4
+        rows, ps = [], []
+        p0 = 0
+        while p0 < pw:
+            wdt = 12 if pw - p0 >= 12 else 4
+            n = np.arange(wdt * th)
+            rows.append(n // wdt)
+            ps.append(p0 + n % wdt)
+            p0 += wdt
+        row, p = np.concatenate(rows), np.concatenate(ps)
+    else:
+        raise ValueError(scheme)
+    return row, p, 2 * p < tw, 2 * p + 1 < tw
+
+
+def simulate(frames, c, scheme):
+    offs = [np.array(s1.stage_offsets(c, j, PITCH0, P12)) for j in range(NST)]
+    cls = [np.bincount(o & 3, minlength=4) for o in offs]  # byte-read constants per (offset mod 4)
+    act = np.zeros(NST)
+    issued = np.zeros(NST)
+    for fr in frames:
+        levels, arena = ho.pyramid(fr)
+        for i in range(len(levels) - 12):
+            death = s1.survivors_for_scale(c, levels, arena, i)
+            if death is None:
+                continue
+            H2, W2 = death.shape
+            tw2, th2, ntx, nty = tile_shapes(W2, H2)
+            for ty in range(nty):
+                for tx in range(ntx):
+                    X0, Y0 = tx * tw2, ty * th2
+                    tw, th = min(tw2, W2 - X0), min(th2, H2 - Y0)
+                    d = death[Y0:Y0 + th, X0:X0 + tw]
+                    row, p, v0, v1 = enum_pairs(scheme, tw2, th, tw)
+                    npairs = len(row)
+                    # waves: contiguous quarters of the 32-pair batches (64 ids), a pass = 64 pairs
+                    nbat = -(-npairs // 32)
+                    per = -(-nbat // 4)
+                    queues = []
+                    for wv in range(4):
+                        lo, hi = min(wv * per * 32, npairs), min((wv * per + per) * 32, npairs)
+                        q_ids = []
+                        for b in range(lo, hi, 64):
+                            e = min(b + 64, hi)
+                            r_, p_, a0, a1 = row[b:e], p[b:e], v0[b:e], v1[b:e]
+                            n = e - b
+                            pad = 64 - n
+                            dw = np.concatenate([np.where(a0, r_ * (PITCH0 // 2) + p_, 0), np.zeros(pad, dtype=np.int64)])  # invalid lanes read at base 0
+                            vv = np.ones(64, dtype=bool)  # every lane issues its read (invalid ones at the tile's base)
+                            cyc = group_cycles_dw(dw.reshape(2, 32), vv.reshape(2, 32)).sum()
+                            act[0] += 30 * cyc
+                            issued[0] += 30 * 2
+                            # survivors: even windows of the pass first, then the odd ones
+                            for a, dx in ((a0, 0), (a1, 1)):
+                                keep = a & (d[np.minimum(r_, th - 1), np.minimum(2 * p_ + dx, tw - 1)] > 0)
+                                q_ids.append(np.stack([r_[keep], 2 * p_[keep] + dx], axis=1))
+                        queues.append(np.concatenate(q_ids) if q_ids else np.zeros((0, 2), dtype=np.int64))
+                    # later stages on the wave-private queues (the <=64 merge is modelled as the same byte reads)
+                    for j in range(1, NST):
+                        for wv in range(4):
+                            q = queues[wv]
+                            if len(q) == 0:
+                                continue
+                            B = 2 * (q[:, 0] * PITCH0 + q[:, 1])
+                            n = len(B)
+                            pad = (-n) % 64
+                            Bp = np.concatenate([B, np.zeros(pad, dtype=np.int64)]).reshape(-1, 32)
+                            vp = np.concatenate([np.ones(n, dtype=bool), np.ones(pad, dtype=bool)]).reshape(-1, 32)
+                            for k in range(4):
+                                if cls[j][k] == 0:
+                                    continue
+                                cyc = group_cycles_dw((Bp + k) >> 2, vp).sum()
+                                act[j] += cls[j][k] * cyc
+                                issued[j] += cls[j][k] * Bp.shape[0]
+                            keep = d[q[:, 0], q[:, 1]] > j
+                            queues[wv] = q[keep]
+    return act, issued
+
+
+def main():
+    nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (320, 240)
+    c = load_cascade()
+    frames = synth.mixed_batch(nframes, w, h, seed0=1234)
+    for scheme in ("rowmajor", "strip4", "strip12"):
+        act, issued = simulate(frames, c, scheme)
+        print(f"{scheme:9s}: LDS cycles {act.sum():.3e} for {issued.sum():.3e} conflict-free -> conflict share {100 * (1 - issued.sum() / act.sum()):.1f} % of all cycles")
+        print("    per stage cycles / conflict-free:", " ".join(f"{a / max(b, 1):.2f}" for a, b in zip(act, issued)), "| share of cycles:", " ".join(f"{100 * a / act.sum():.0f}%" for a in act))
+
+
+if __name__ == "__main__":
+    main()

@@ -702,7 +702,7 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
     uint64_t qc = c->queue_capacity_cfg ? c->queue_capacity_cfg : std::max<uint64_t>(1u << 16, c->windows_per_frame * (uint64_t)max_batch / 8);
     qc = std::min<uint64_t>(qc, 1ull << 28);
     c->queue_capacity = (uint32_t)qc;
-    if (hipMalloc(&c->d_queue, (size_t)qc * sizeof(HtQueueEntry)) != hipSuccess)
+    if (hipMalloc(&c->d_queue, (size_t)qc * sizeof(HtQueueEntry) + HT_DEEP_CTR_BYTES) != hipSuccess)  // + the deep kernel's work counters
         return ht_fail(c, HT_ERR_NOMEM, "ht_set_geometry: hipMalloc(survivor queue) failed");
     return HT_OK;
 }

@@ -174,6 +174,11 @@ struct HtQueueEntry {
 };
 static_assert(sizeof(HtQueueEntry) == 16, "HtQueueEntry");
 
+// k_scan_deep_lds hands its queue entries out through HT_DEEP_CTRS counters, one per 256-byte line, in the 4 KB behind the queue's
+// last entry (zeroed by the first workgroup of every k_scan_tiles launch): same-address atomics retire at ~90 per us, one counter for
+// the 6 103 windows of a C2 batch made the launch 0.10 ms long whatever the grid.
+#define HT_DEEP_CTRS 16
+#define HT_DEEP_CTR_BYTES (HT_DEEP_CTRS * 256)
 #define HT_PINNED_HITS 8192
 #define HT_STAT_SHARDS 256  // rows of 64 u64 counters; a workgroup adds to row (blockIdx & 255)
 

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     // XCD-aware tile order: consecutive tiles (same frame / scale, shared halos) stay on one XCD's L2.
     const uint32_t nb = gridDim.x, chunk = nb >> 3;  // gridDim.x is a multiple of 8
     const uint32_t t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+    if (blockIdx.x == 0 && threadIdx.x < HT_DEEP_CTRS) reinterpret_cast<uint32_t *>(queue + queue_cap)[threadIdx.x * 64u] = 0u;  // k_scan_deep_lds' work counters
     if (t >= total_tiles) return;
     const uint32_t frame = t / tiles_per_frame, lt = t - frame * tiles_per_frame;
     const HtTileRec R = tile_recs[lt];  // one 64-byte scalar load: everything about the tile
@@ -924,9 +925,27 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
     const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the patch address, the queue index and the statistics row become scalar registers
     uint8_t *patch = per_wave + wv * (PATCH_BYTES + 512);
     double *sel_buf = reinterpret_cast<double *>(patch + PATCH_BYTES);
-    const uint32_t wave = blockIdx.x * DEEPL_WAVES + wv, nwaves = gridDim.x * DEEPL_WAVES;
+    const uint32_t wave = blockIdx.x * DEEPL_WAVES + wv, nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * DEEPL_WAVES));
     unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
-    for (uint32_t e = wave; e < n; e += nwaves) {
+    // Queue entries are handed out dynamically: a wavefront's first window is entry `wave`, every further one comes from a counter.
+    // A window that survives all 16 stages costs ~43 k cycles, one that dies in the stage it was handed over at ~6 k, and a C2 batch
+    // queues 6 103 windows (1 392 full survivors) for the 2 304 wavefronts of the 192-workgroup grid: with the fixed stride
+    // e += nwaves the launch lasted as long as the wavefront that drew three full survivors (0.055 ms).  The counter is read one
+    // window ahead (the atomic's round trip is hidden behind the window being evaluated); HT_DEEP_CTRS counters, each handing out
+    // every HT_DEEP_CTRS-th entry to the wavefronts that share it (see ht_internal.h).
+#ifndef HT_DEEP_DYNAMIC
+#define HT_DEEP_DYNAMIC 1
+#endif
+    const uint32_t *my_ctr = reinterpret_cast<const uint32_t *>(queue + queue_cap) + (wave & (HT_DEEP_CTRS - 1u)) * 64u;
+    for (uint32_t e = wave; e < n;) {
+        e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);  // the queue entry is a scalar load
+        uint32_t nxt = 0;
+        if (HT_DEEP_DYNAMIC && lane == 0) {
+            // written out: atomicAdd() is turned into a wave-aggregated add whose result is waited for on the spot (~2 us per window);
+            // the compiler's own s_waitcnt vmcnt(k) stay correct with one more (older) operation in the in-order queue
+            const uint32_t zero = 0u, one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(nxt) : "v"(zero), "v"(one), "s"(my_ctr) : "memory");
+        }
         const HtQueueEntry ent = queue[e];
         uint32_t ln = lane;  // the gathers' index arithmetic from an opaque lane number: as loop invariants it would be hoisted out of the window
         asm volatile("" : "+v"(ln));  // loop and held (spilled, at this budget) across the stage passes
@@ -961,6 +980,13 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
                 if (i < 144u) patch[PATCH1 + i] = (uint8_t)pb[k];
             }
             if (ln < 36u) patch[PATCH2 + ln] = (uint8_t)pc;
+            // the next entry's index has arrived with the gathers (issued before them): parked in the patch's spare bytes, not in a
+            // register that would live across the stage passes (at 80 VGPRs that one register was 9 spills)
+            static_assert(PATCH2 + 36 <= 760 && PATCH_BYTES >= 764, "spare bytes of the patch");
+            if (HT_DEEP_DYNAMIC && lane == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt) : : "memory");  // the gathers before it in the queue have been consumed above
+                *reinterpret_cast<uint32_t *>(&patch[760]) = nxt;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1078,6 +1104,14 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
         dl_first = false;
 #endif
         __builtin_amdgcn_wave_barrier();
+        if (HT_DEEP_DYNAMIC) {
+            uint32_t po = 760u;
+            asm volatile("" : "+s"(po));  // an address the optimiser cannot match with the store above: a real LDS read, not a register held across the window
+            // the k-th entry handed out by counter c is nwaves + HT_DEEP_CTRS * k + c
+            e = nwaves + HT_DEEP_CTRS * (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t *>(patch + po)) + (wave & (HT_DEEP_CTRS - 1u));
+        } else {
+            e += nwaves;
+        }
     }
 }
 

@@ -243,8 +243,9 @@ class Context:
         return out
 
     def camshift_track_collect(self, n: int):
-        """Track objects of the last camshift_track(n, fetch=False): waits for it.  Lets a host enqueue the track() of several
-        feeds (contexts) first and collect afterwards."""
+        """Track objects of the OLDEST outstanding camshift_track(n, fetch=False): waits for that call only.  Up to 4 enqueue-only calls
+        may be outstanding (results land in a ring of pinned slots), so a streaming host enqueues step i + 1 before it waits for step i,
+        and a host with several feeds (contexts) enqueues every feed's track() first and collects afterwards."""
         out = np.zeros(n, dtype=native.CS_TRACKOBJ_DTYPE)
         self._check(self._lib.ht_camshift_track_collect(self._h, n, out.ctypes.data))
         return out

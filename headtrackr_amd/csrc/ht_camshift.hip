@@ -704,6 +704,7 @@ __global__ __launch_bounds__(512) void k_cs_lut(const uint32_t *__restrict__ his
 struct ClusterSync {
     unsigned long long *counter;
     uint32_t *err;
+    uint32_t *err_host;  // pinned host word (plain system-scope store of 1): an enqueue-only call's host side reads it without a copy
     long long budget;
     int *s_timeout;  // LDS flag of the workgroup
 };
@@ -771,6 +772,7 @@ __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img,
                     if ((long long)__builtin_readcyclecounter() - t0 > sync.budget) {  // bounded spin: give up, flag it, never wait again
                         *sync.s_timeout = 1;
                         atomicOr(sync.err, 1u);
+                        if (sync.err_host) __hip_atomic_store(sync.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(2);
@@ -796,7 +798,8 @@ __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img,
 __global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H, const double *__restrict__ lut_g,
                                                                 HtCsState *__restrict__ states, int first, int calc_angles, int max_it, int G,
                                                                 double *__restrict__ parts, unsigned long long *__restrict__ counters,
-                                                                uint32_t *__restrict__ err, long long budget, ht_cs_trackobj *__restrict__ out) {
+                                                                uint32_t *__restrict__ err, uint32_t *__restrict__ err_host, long long budget,
+                                                                ht_cs_trackobj *__restrict__ out) {
     __shared__ double lut[4096];
     __shared__ double red[6][CL_NT / 64];
     __shared__ double s_part[CL_MAXG * 6];
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *_
     if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
     __syncthreads();
     double *my_parts = parts + (size_t)s * CL_SLOTS * CL_MAXG * 6;
-    const ClusterSync sync = {counters + s, err, budget, &s_timeout};
+    const ClusterSync sync = {counters + s, err, err_host, budget, &s_timeout};
     int slot = 0;
     meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, g == 0, [&](int x, int y, int w, int h) {
         const int sl = slot++;
@@ -839,8 +842,10 @@ ClusterGate &cluster_gate() {
 
 // fetched with every result read-back: a cluster barrier that ran out of its cycle budget surfaces as a status code
 ht_status cs_check_err(ht_ctx *c, const char *where) {
-    if (!c->h_cs_err || *c->h_cs_err == 0) return HT_OK;
-    *c->h_cs_err = 0;
+    const bool direct = c->h_cs_err_direct && __atomic_load_n(c->h_cs_err_direct, __ATOMIC_ACQUIRE) != 0;
+    if (!direct && (!c->h_cs_err || *c->h_cs_err == 0)) return HT_OK;
+    if (c->h_cs_err) *c->h_cs_err = 0;
+    if (c->h_cs_err_direct) __atomic_store_n(c->h_cs_err_direct, 0u, __ATOMIC_RELEASE);
     (void)hipMemsetAsync(c->d_cs_err, 0, sizeof(uint32_t), c->stream);
     return ht_fail(c, HT_ERR_STATE, std::string(where) + ": a camshift cluster barrier timed out (workgroups of one stream were not co-resident); the affected streams' state is undefined — re-initialise them");
 }
@@ -895,6 +900,23 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
     c->d_cs_err = nerr, c->h_cs_err = herr;
     c->cs_last_n = c->cs_last_chunks = 0;  // the debug histogram buffer is new
     c->cs_streams = nstreams;
+    // result ring of the enqueue-only track calls (the stream was synchronised above: no slot is in use; uncollected results are dropped)
+    c->cs_ring_head = c->cs_ring_count = 0;
+    if (!c->h_cs_err_direct) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_cs_err_direct), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+            return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_reserve: hipHostMalloc failed");
+        *c->h_cs_err_direct = 0;
+    }
+    for (auto &sl : c->cs_ring) {
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        sl.h_out = nullptr;
+        if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_out), sizeof(ht_cs_trackobj) * (size_t)nstreams, hipHostMallocDefault) != hipSuccess) {
+            c->cs_ring_streams = 0;
+            return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_reserve: hipHostMalloc failed");
+        }
+        if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return ht_fail(c, HT_ERR_HIP, "ht_camshift_reserve: hipEventCreate failed");
+    }
+    c->cs_ring_streams = nstreams;
     return HT_OK;
 }
 
@@ -904,8 +926,7 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
     if (!c->d_frames || n <= 0 || n > c->nframes) return ht_fail(c, HT_ERR_STATE, "ht_camshift_init_batch: bind n frames first");
     if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_init_batch: stream range not reserved");
     HT_HIP(c, hipSetDevice(c->device));
-    ht_cs_rect *d_rects = reinterpret_cast<ht_cs_rect *>(c->d_cs_out);  // scratch: sizeof(ht_cs_trackobj) >= sizeof(ht_cs_rect)
-    c->cs_track_pending_n = 0;  // ... which overwrites the results of an uncollected enqueue-only track call
+    ht_cs_rect *d_rects = reinterpret_cast<ht_cs_rect *>(c->d_cs_out);  // scratch: sizeof(ht_cs_trackobj) >= sizeof(ht_cs_rect); enqueue-only track calls keep their results in the pinned ring
     HT_HIP(c, hipMemcpyAsync(d_rects, rects, sizeof(ht_cs_rect) * (size_t)n, hipMemcpyHostToDevice, c->stream));
     {
         HtProfScope ps(c, "cs_init");
@@ -974,7 +995,7 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
         if (!ev) HT_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         else HT_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));  // the previous cluster grid on this device (any context) has drained
         hipLaunchKernelGGL(k_cs_meanshift_cluster, dim3(n * G), dim3(CL_NT), 0, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_lut, c->d_cs, first,
-                           calc_angles, c->dbg_cs_iters, G, c->d_cs_parts, c->d_cs_ctr, c->d_cs_err, (long long)c->cs_barrier_budget, d_out);
+                           calc_angles, c->dbg_cs_iters, G, c->d_cs_parts, c->d_cs_ctr, c->d_cs_err, c->h_cs_err_direct, (long long)c->cs_barrier_budget, d_out);
         HT_HIP(c, hipGetLastError());
         HT_HIP(c, hipEventRecord(ev, c->stream));
     } else {
@@ -994,9 +1015,19 @@ extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n
     if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_track_batch: stream range not reserved");
     if (c->W == 0 || c->H == 0) return HT_OK;  // camshift.js:219
     HT_HIP(c, hipSetDevice(c->device));
+    if (!out) {  // enqueue only: results go straight to the next pinned slot, an event marks them complete
+        if (c->cs_ring_count == ht_ctx::HT_CS_RING || n > c->cs_ring_streams)
+            return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_batch: too many enqueue-only calls outstanding (collect with ht_camshift_track_collect)");
+        ht_ctx::HtCsSlot &sl = c->cs_ring[(c->cs_ring_head + c->cs_ring_count) % ht_ctx::HT_CS_RING];
+        ht_status st = launch_track(c, c->d_frames, c->frame_stride, first, n, calc_angles, sl.h_out);
+        if (st != HT_OK) return st;
+        HT_HIP(c, hipEventRecord(sl.ev, c->stream));
+        sl.n = n;
+        c->cs_ring_count++;
+        return HT_OK;
+    }
     ht_status st = launch_track(c, c->d_frames, c->frame_stride, first, n, calc_angles, c->d_cs_out);
     if (st != HT_OK) return st;
-    c->cs_track_pending_n = out ? 0 : n;
     if (out) {
         HT_HIP(c, hipMemcpyAsync(out, c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
         HT_HIP(c, hipMemcpyAsync(c->h_cs_err, c->d_cs_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
@@ -1009,12 +1040,14 @@ extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n
 extern "C" ht_status ht_camshift_track_collect(ht_ctx *c, int32_t n, ht_cs_trackobj *out) {
     HtRange range("ht_camshift_track_collect");
     if (!c || !out || n <= 0) return HT_ERR_INVALID;
-    if (c->cs_track_pending_n != n) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_collect: no enqueue-only ht_camshift_track_batch of n streams is pending");
+    if (c->cs_ring_count == 0 || c->cs_ring[c->cs_ring_head].n != n)
+        return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_collect: no enqueue-only ht_camshift_track_batch of n streams is pending");
     HT_HIP(c, hipSetDevice(c->device));
-    HT_HIP(c, hipMemcpyAsync(out, c->d_cs_out, sizeof(ht_cs_trackobj) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
-    HT_HIP(c, hipMemcpyAsync(c->h_cs_err, c->d_cs_err, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HT_HIP(c, hipStreamSynchronize(c->stream));
-    c->cs_track_pending_n = 0;
+    ht_ctx::HtCsSlot &sl = c->cs_ring[c->cs_ring_head];
+    HT_HIP(c, hipEventSynchronize(sl.ev));  // the OLDEST outstanding call; later ones keep running
+    std::memcpy(out, sl.h_out, sizeof(ht_cs_trackobj) * (size_t)n);
+    c->cs_ring_head = (c->cs_ring_head + 1) % ht_ctx::HT_CS_RING;
+    c->cs_ring_count--;
     return cs_check_err(c, "ht_camshift_track_collect");
 }
 

@@ -427,6 +427,11 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->h_wb_pinned) (void)hipHostFree(c->h_wb_pinned);
     if (c->d_cs_err) (void)hipFree(c->d_cs_err);
     if (c->h_cs_err) (void)hipHostFree(c->h_cs_err);
+    if (c->h_cs_err_direct) (void)hipHostFree(c->h_cs_err_direct);
+    for (auto &sl : c->cs_ring) {
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.ev) (void)hipEventDestroy(sl.ev);
+    }
     if (c->d_cs) (void)hipFree(c->d_cs);
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);

@@ -356,7 +356,18 @@ struct ht_ctx {
     size_t cs_seq_cap = 0;
     // the sequence enqueued with out == NULL that ht_camshift_sequence_collect may fetch (n == 0: none pending)
     int cs_seq_pending_n = 0, cs_seq_pending_calls = 0, cs_seq_pending_all = 0;
-    int cs_track_pending_n = 0;        // streams of the ht_camshift_track_batch enqueued with out == NULL (ht_camshift_track_collect)
+    // enqueue-only track calls (ht_camshift_track_batch with out == NULL): the kernels write their track objects straight into a pinned
+    // host slot of this ring, an event marks the slot complete; ht_camshift_track_collect takes the oldest.  Up to HT_CS_RING calls may be
+    // outstanding, so a streaming host enqueues step i + 1 before it waits for step i.
+    static constexpr int HT_CS_RING = 4;
+    struct HtCsSlot {
+        ht_cs_trackobj *h_out = nullptr;  // pinned, cs_ring_streams objects
+        hipEvent_t ev = nullptr;
+        int n = 0;
+    };
+    HtCsSlot cs_ring[HT_CS_RING];
+    int cs_ring_head = 0, cs_ring_count = 0, cs_ring_streams = 0;
+    uint32_t *h_cs_err_direct = nullptr;  // pinned word the cluster kernel itself sets when a barrier times out (read with a ring slot: no copy)
     uint32_t *d_cs_err = nullptr;      // device word: a cluster barrier ran out of its cycle budget (k_cs_meanshift_cluster)
     uint32_t *h_cs_err = nullptr;      // pinned copy, fetched with every result read-back
     long long cs_barrier_budget = 1ll << 28;  // shader-clock cycles a workgroup waits at one cluster barrier (option cs_barrier_budget)

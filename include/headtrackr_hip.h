@@ -225,9 +225,12 @@ ht_status ht_camshift_reserve(ht_ctx *ctx, int32_t nstreams);
 ht_status ht_camshift_init_batch(ht_ctx *ctx, int32_t first, int32_t n, const ht_cs_rect *rects);
 /* track (camshift.js:213-312) for streams [first, first+n) on bound frames [0, n); out[n] (may be NULL: enqueue only). */
 ht_status ht_camshift_track_batch(ht_ctx *ctx, int32_t first, int32_t n, int32_t calc_angles, ht_cs_trackobj *out);
-/* Results of the last ht_camshift_track_batch that was enqueued with out == NULL (same n): waits for it and copies the track objects.
- * A host that serves several feeds on several contexts enqueues every feed's track() first and collects afterwards, so the feeds'
- * kernels overlap on the GPU (the reference's loop, main.js:168-180, is one feed; this is its K-feed form). */
+/* Results of the OLDEST outstanding ht_camshift_track_batch that was enqueued with out == NULL (same n): waits for that call only and
+ * copies its track objects.  Up to 4 enqueue-only calls may be outstanding per context (a fifth fails with HT_ERR_STATE): their kernels
+ * write the track objects into a ring of pinned host slots, so a streaming host enqueues the track() of frame i + 1 before it waits for
+ * frame i (the search window that links them lives on the device), and a host that serves several feeds on several contexts enqueues every
+ * feed's track() first and collects afterwards (the reference's loop, main.js:168-180, is one feed; this is its K-feed form).
+ * ht_camshift_reserve drops uncollected results. */
 ht_status ht_camshift_track_collect(ht_ctx *ctx, int32_t n, ht_cs_trackobj *out);
 /* ncalls successive track() calls (camshift.js:213-220 called once per video frame, main.js:168-180) for streams
  * [first, first+n) in ONE host call: call k uses the n device-resident frames at dev_frames[k] (frame_stride bytes apart;

@@ -90,6 +90,69 @@ def test_c5_shape_feeds_in_one_context_vs_oracle(cascade, feeds):
         dev.free()
 
 
+def test_enqueue_only_track_calls_pipeline_through_the_result_ring(cascade):
+    """bench.py's timed C5 loop keeps TWO track steps outstanding (step i + 1 is enqueued before step i is collected); the library allows
+    four (results in a ring of pinned slots the kernels write directly).  Here: 4 feeds x 1080p, detect + initTracker, then the 29 track
+    steps of a cycle enqueued 4 / 2 / 1 deep — every collected object is the oracle's for THAT step (oldest first), a fifth outstanding
+    call and a collect with nothing pending are refused with HT_ERR_STATE, and initTracker between enqueue and collect loses nothing."""
+    from headtrackr_amd.api import HtError
+
+    K = 4
+    uniq = synth.stream_feed_frames(NUNIQ, W, H, 0)
+    c = Context()
+    dev = c5_device_steps(uniq, K)
+    sbytes = K * W * H * 4
+    try:
+        c.set_geometry(W, H, K)
+        c.camshift_reserve(K)
+        with pytest.raises(HtError):
+            c.camshift_track_collect(K)  # nothing pending
+        stats = []
+        for depth in (4, 2, 1):
+            c.bind_device(dev.ptr, K)
+            c.detect_enqueue(0)
+            best = c.detect_collect_best(1)[0].copy()
+            rects = floored_rects(best, W, H)
+            c.camshift_init(rects)
+            oracles = []
+            for f in range(K):
+                o = ho.Camshift(True)
+                o.init_tracker(uniq[synth.stream_frame_index(0, f, NUNIQ)], rects[f])
+                oracles.append(o)
+            pend = []
+
+            def collect_oldest():
+                j = pend.pop(0)
+                got = c.camshift_track_collect(K)
+                for f in range(K):
+                    sw, to = oracles[f].track(uniq[synth.stream_frame_index(j, f, NUNIQ)])
+                    cs_check(got[f], sw, to, stats, where=("ring", depth, f, j))
+
+            for i in range(1, 30):
+                c.bind_device(dev.ptr + (i % NUNIQ) * sbytes, K)
+                c.camshift_track(K, calc_angles=True, fetch=False)
+                pend.append(i)
+                if depth == 4 and len(pend) == 4 and i == 4:
+                    with pytest.raises(HtError):
+                        c.camshift_track(K, calc_angles=True, fetch=False)  # a fifth outstanding call
+                while len(pend) >= depth:
+                    collect_oldest()
+            while pend:
+                collect_oldest()
+        assert len(stats) == 3 * 29 * K
+        cs_all_exact(stats, "enqueue-only track calls 4 / 2 / 1 deep, 4 x 1080p feeds")
+        # initTracker between enqueue and collect: the pending results are still those of the track call
+        c.bind_device(dev.ptr + sbytes, K)
+        c.camshift_track(K, calc_angles=True, fetch=False)
+        want = c.camshift_track(K, calc_angles=True, fetch=True)  # the same frames again, synchronously: the NEXT call of every stream
+        c.camshift_init(floored_rects(best, W, H))
+        got = c.camshift_track_collect(K)
+        assert got.shape == want.shape and all(got["width"] > 0)
+    finally:
+        c.close()
+        dev.free()
+
+
 @pytest.mark.parametrize("wb", [False, True], ids=["plain", "whitebalance"])
 @pytest.mark.parametrize("w,h,n", [(320, 240, 3), (322, 241, 2), (1920, 1080, 1)])
 def test_graph_replay_equals_plain_enqueue(cascade, wb, w, h, n):

@@ -346,7 +346,7 @@ headtrackr.ccv.detect_objects_batch = function (frames, n, w, h, cascade, interv
  *                                           last batch, hits, batches}; neighbors 0 / confidence -10000 = no face (facetrackr.js:239)
  *     detect(min_neighbors, set)           -> Array<Array<rect>>: exactly ccv.detect_objects' result per frame (parity path)
  *     whitebalance(set)                    -> Float64Array(n): getWhitebalance per frame, fused into a detect batch's gray pass
- *     detectStep(set) / trackStep(set) / ingest(pinned) / swap()   K frame-synchronous live feeds, one time step per call (below)
+ *     detectStep(set) / trackStep(set) / trackEnqueue(set) + trackCollect() / ingest(pinned) / swap()   K frame-synchronous live feeds, one time step per call (below)
  *     initTrackers(rects, set) / trackSequence(sets[], calcAngles, outAll) -> Float64Array(9 n [* calls]): n camshift streams,
  *                                           one track() per listed frame set, ONE host call (ht_camshift_track_sequence)
  *     destroy() */
@@ -442,6 +442,14 @@ headtrackr.ccv.DeviceBatch = function (w, h, n, opts) {
     A.camshiftTrackBound(ctxs[0], n, 0, calcAngles === false ? 0 : 1, false);
     return A.camshiftTrackCollect(ctxs[0], n);
   };
+  /*   trackEnqueue(set, calcAngles) / trackCollect()   the two halves of trackStep: up to 4 track steps may be outstanding (the library
+   *                                  keeps their results in a ring of pinned slots; trackCollect returns the OLDEST), so a streaming host
+   *                                  enqueues step i + 1 before it waits for step i — the search window that links them lives on the GPU */
+  this.trackEnqueue = function (set, calcAngles) {
+    bind0(set === undefined ? 0 : set);
+    A.camshiftTrackBound(ctxs[0], n, 0, calcAngles === false ? 0 : 1, false);
+  };
+  this.trackCollect = function () { return A.camshiftTrackCollect(ctxs[0], n); };
   this.graphLaunches = function () { return ctxs.reduce(function (s, c) { return s + A.graphLaunches(c); }, 0); };
   /* the frame buffer is shared by all `depth` contexts: the others go first (ht_device_free refuses while they have it bound) */
   this.destroy = function () { for (let i = ctxs.length - 1; i >= 1; i--) A.destroy(ctxs[i]); A.deviceFree(ctxs[0], dev); A.destroy(ctxs[0]); ctxs.length = 0; };

@@ -46,7 +46,13 @@ constexpr int CS_NT = 512;          // threads of the mean-shift workgroup
 constexpr int HIST_NT = 256;
 // Partial histograms per stream: enough chunks to put ~1024 workgroups on the chip (a single 1080p stream gets 127, a
 // batch of >= 128 streams 8 each), each chunk >= 16384 pixels and a multiple of 4 * HIST_NT.
-inline uint32_t hist_max_chunks(int nstreams) { return (uint32_t)std::min(128, std::max(8, 1024 / std::max(nstreams, 1))); }
+#ifndef HT_HIST_MAXCHUNKS
+#define HT_HIST_MAXCHUNKS 128
+#endif
+#ifndef HT_HIST_UNROLL
+#define HT_HIST_UNROLL 4
+#endif
+inline uint32_t hist_max_chunks(int nstreams) { return (uint32_t)std::min(HT_HIST_MAXCHUNKS, std::max(8, (HT_HIST_MAXCHUNKS * 8) / std::max(nstreams, 1))); }
 inline void hist_chunks(uint32_t npix, uint32_t max_chunks, uint32_t *chunk_px, uint32_t *nchunks) {
     uint32_t n = std::min<uint32_t>((npix + 16383u) / 16384u, max_chunks);
     n = std::max<uint32_t>(n, 1u);
@@ -178,19 +184,32 @@ __global__ __launch_bounds__(HIST_NT) void k_cs_hist(const uint8_t *__restrict__
     const uint32_t nquad = (end - beg) / 4;
     const uint4 *img4 = reinterpret_cast<const uint4 *>(frame + (size_t)beg * 4);
     const uint32_t iters = chunk_px / (4 * HIST_NT);
-#pragma unroll 4
-    for (uint32_t it = 0; it < iters; it++) {
-        const uint32_t i = it * HIST_NT + threadIdx.x;
-        const bool on = i < nquad;
-        uint4 p = make_uint4(0u, 0u, 0u, 0u);
-        if (on) p = img4[i];
-        const uint32_t b0 = cs_bin(p.x), b1 = cs_bin(p.y), b2 = cs_bin(p.z), b3 = cs_bin(p.w);
-        const bool flat = (b0 == b1) && (b2 == b3) && (b0 == b2);
-        hist_add_wave(h, b0, flat ? 4u : 1u, on);
-        if (on && !flat) {
-            atomicAdd(&h[b1], 1u);
-            atomicAdd(&h[b2], 1u);
-            atomicAdd(&h[b3], 1u);
+    // HT_HIST_UNROLL loads of a thread in flight before the first bin is counted, written out: the wave-level merge below is convergent code,
+    // which keeps the optimiser from unrolling the loop itself (`#pragma unroll` was refused), and with ONE 16-byte load in flight per
+    // thread the pass was a chain of chunk_px / 1024 memory round trips (16 x ~1.3 us at 1080p = the kernel's whole duration)
+    for (uint32_t it0 = 0; it0 < iters; it0 += HT_HIST_UNROLL) {
+        uint4 pv[HT_HIST_UNROLL];
+        bool onv[HT_HIST_UNROLL];
+#pragma unroll
+        for (int u = 0; u < HT_HIST_UNROLL; u++) {
+            const uint32_t i = (it0 + (uint32_t)u) * HIST_NT + threadIdx.x;
+            onv[u] = it0 + (uint32_t)u < iters && i < nquad;
+            pv[u] = make_uint4(0u, 0u, 0u, 0u);
+            if (onv[u]) pv[u] = img4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < HT_HIST_UNROLL; u++) {
+            if (it0 + (uint32_t)u >= iters) break;  // workgroup-uniform
+            const uint4 p = pv[u];
+            const bool on = onv[u];
+            const uint32_t b0 = cs_bin(p.x), b1 = cs_bin(p.y), b2 = cs_bin(p.z), b3 = cs_bin(p.w);
+            const bool flat = (b0 == b1) && (b2 == b3) && (b0 == b2);
+            hist_add_wave(h, b0, flat ? 4u : 1u, on);
+            if (on && !flat) {
+                atomicAdd(&h[b1], 1u);
+                atomicAdd(&h[b2], 1u);
+                atomicAdd(&h[b3], 1u);
+            }
         }
     }
     const uint32_t *img = reinterpret_cast<const uint32_t *>(frame);

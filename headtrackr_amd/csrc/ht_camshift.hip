@@ -691,9 +691,10 @@ constexpr int CL_NT = 512, CL_MAXG = 32, CL_SLOTS = 12;  // <= 11 moment passes 
 // weight LUT of every stream from its chunk histograms (getWeights, camshift.js:314-330): grid (64, streams) x 512 threads;
 // a block owns 64 bins, its 8 wavefronts each sum every 8th chunk (a single 1080p stream has 127 chunk histograms = 2 MB)
 __global__ __launch_bounds__(512) void k_cs_lut(const uint32_t *__restrict__ hist, int nchunks, const HtCsState *__restrict__ states, int first,
-                                                double *__restrict__ lut) {
+                                                double *__restrict__ lut, unsigned long long *__restrict__ cluster_ctr) {
     __shared__ uint32_t part[8][64];
     const int s = blockIdx.y, lane = threadIdx.x & 63, grp = threadIdx.x >> 6, bin = blockIdx.x * 64 + lane;
+    if (blockIdx.x == 0 && threadIdx.x == 0) cluster_ctr[s] = 0ull;  // the stream's arrival counter of the cluster launch that follows (was a memset of its own)
     const uint32_t *cur = hist + (size_t)s * nchunks * 4096 + bin;
     uint32_t ch = 0;
 #pragma unroll 4
@@ -1003,8 +1004,7 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
     if (c->cs_cluster && n <= 64 && G >= 4 && npix >= c->cs_cluster_min_px && c->dbg_cs_iters > 0) {
         {
             HtProfScope ps(c, "cs_lut");
-            HT_HIP(c, hipMemsetAsync(c->d_cs_ctr, 0, sizeof(unsigned long long) * (size_t)n, c->stream));
-            hipLaunchKernelGGL(k_cs_lut, dim3(64, n), dim3(512), 0, c->stream, c->d_cs_hist, (int)nchunks, c->d_cs, first, c->d_cs_lut);
+            hipLaunchKernelGGL(k_cs_lut, dim3(64, n), dim3(512), 0, c->stream, c->d_cs_hist, (int)nchunks, c->d_cs, first, c->d_cs_lut, c->d_cs_ctr);
             HT_HIP(c, hipGetLastError());
         }
         HtProfScope ps(c, "cs_meanshift");

@@ -24,6 +24,9 @@ traffic = {"_note": "HBM bytes from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (s
            "On gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section); calibrated on k_gray_linear, whose traffic is known exactly "
            "(reads W*H*4, writes W*H per frame): gray_check.  per_step: bytes per detect step and bench timer name = every launch's OWN counters summed over the "
            "launches the timer covers (resample = the k_resample launches + the tail kernel); per_launch: mean per launch and kernel."}
+ks5 = glob.glob(os.path.join(G, "prof_c5", "**", "*kernel_stats.csv"), recursive=True)  # C5 (8 x 1080p feeds): kernel stats only
+if ks5:
+    shutil.copy(ks5[0], os.path.join(P, f"{tag}_c5_kernel_stats.csv"))
 for wl in ("c2", "c4", "c3"):
     ks = glob.glob(os.path.join(G, f"prof_{wl}", "**", "*kernel_stats.csv"), recursive=True)
     if ks:

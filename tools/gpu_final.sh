@@ -21,9 +21,10 @@ for o in "" host_threads=0; do timeout 120 python tools/gpu_kernel_times.py c2 $
 timeout 120 python tools/gpu_kernel_times.py c4 2>/dev/null | tail -1 >> $OUT/kernel_times.txt; cat $OUT/kernel_times.txt
 if [ "${RUN_PROF:-1}" = 1 ]; then
 cd /tmp
-for wl in c2 c4 c3; do
-  ST=8; [ $wl = c3 ] && ST=2
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_$wl -o $wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl --steps $ST --warmup 2 --cpu-seconds 0 --prewarm 0 --pipeline 1 --no-sub > $GRAFT_REPO_ROOT/$OUT/prof_$wl.log 2>&1
+for wl in c2 c4 c3 c5; do
+  ST=8; [ $wl = c3 ] && ST=2; [ $wl = c5 ] && ST=60
+  FE=""; [ $wl = c5 ] && FE="--feeds 8"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_$wl -o $wl -- python $GRAFT_REPO_ROOT/bench.py --workload $wl $FE --steps $ST --warmup 2 --cpu-seconds 0 --prewarm 0 --pipeline 1 --no-sub > $GRAFT_REPO_ROOT/$OUT/prof_$wl.log 2>&1
   echo "rocprofv3 stats $wl exit $?"
 done
 cd $GRAFT_REPO_ROOT

@@ -1035,7 +1035,8 @@ extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n
     if (c->W == 0 || c->H == 0) return HT_OK;  // camshift.js:219
     HT_HIP(c, hipSetDevice(c->device));
     if (!out) {  // enqueue only: results go straight to the next pinned slot, an event marks them complete
-        if (c->cs_ring_count == ht_ctx::HT_CS_RING || n > c->cs_ring_streams)
+        if (n > c->cs_ring_streams) return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_batch: no result ring for this many streams (ht_camshift_reserve failed to allocate it)");
+        if (c->cs_ring_count == ht_ctx::HT_CS_RING)
             return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_batch: too many enqueue-only calls outstanding (collect with ht_camshift_track_collect)");
         ht_ctx::HtCsSlot &sl = c->cs_ring[(c->cs_ring_head + c->cs_ring_count) % ht_ctx::HT_CS_RING];
         ht_status st = launch_track(c, c->d_frames, c->frame_stride, first, n, calc_angles, sl.h_out);

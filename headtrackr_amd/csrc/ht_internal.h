@@ -305,7 +305,7 @@ struct ht_ctx {
     int nframes = 0;
     // small batches (a live feed = 1 frame) are launch-bound: ~10 dependent launches cost more than their kernels.  Their sequence is
     // captured into a hipGraph per (frames pointer, count, flags) and replayed.  0 disables (option graph_max_frames)
-    int graph_max_frames = 16;
+    int graph_max_frames = 256;  // round 4: replaying a 256-frame C2 batch instead of launching its 9 kernels: 0.2253 -> 0.2239 ms per step at three in flight (16 until then: only launch-bound small batches)
     std::vector<HtDetectGraph> graphs;
     uint64_t graph_launches = 0;  // measurement: enqueues served by a graph replay
     int64_t requeue_flags = -1;   // >= 0: ht_detect_collect enqueues the next batch (these flags) as soon as the raw hits are on the host

@@ -67,7 +67,7 @@ typedef struct ht_config {
                              *   cs_seq_fused=0|1     track sequences inside one launch (1)       cs_keep_hist=1   keep histograms for ht_camshift_debug_hist
                              *   cs_cluster=0|1, cs_cluster_min_px=N, cs_region=N                 cluster / LDS-region paths of the few-stream schedule
                              *   cs_barrier_budget=N  shader-clock cycles a cluster barrier may wait before the call fails with HT_ERR_STATE
-                             *   graph_max_frames=N   batches up to N frames replay a captured hipGraph (16; 0 = never)
+                             *   graph_max_frames=N   batches up to N frames replay a captured hipGraph (256; 0 = never)
                              *   split=S, deep_bias=B, deep_v=2|4, deep_grid=N                    tile kernel -> deep kernel hand-off
                              *   force_exact=1        every integer stage decision re-run on the sequential binary64 path
                              *   early_scan=1, rs_rpt, rs_minwg, rs_k, rs_group, rs_tailtable, rs_tailcap, rs_notail, rs_nofast, rs_nosort, rs_gennames

@@ -153,6 +153,36 @@ def test_enqueue_only_track_calls_pipeline_through_the_result_ring(cascade):
         dev.free()
 
 
+def test_graph_replay_of_a_full_c2_batch(cascade):
+    """Batches up to 256 frames replay a captured graph by default (the C2 headline batch): the replayed batch's raw hits, per-frame counts and
+    best faces are those of plain launches, also through the collect-and-requeue call the bench loop uses."""
+    frames = synth.mixed_batch(256, 320, 240, seed0=1234)
+    plain = Context(options="graph_max_frames=0")
+    c = Context()
+    try:
+        for cx in (plain, c):
+            cx.set_geometry(320, 240, 256)
+            cx.upload(frames)
+        plain.detect_enqueue(0)
+        want, want_counts = plain.detect_collect()
+        plain.detect_enqueue(0)
+        want_best = plain.detect_collect_best(1)[0].copy()
+        for rep in range(3):
+            c.detect_enqueue(0)
+            got, counts = c.detect_collect()
+            assert got.tobytes() == want.tobytes() and np.array_equal(counts, want_counts), rep
+        assert c.graph_launches == 2
+        c.detect_enqueue(0)
+        for rep in range(3):
+            best = c.detect_collect_best_requeue(1)[0]
+            assert best.tobytes() == want_best.tobytes(), rep
+        assert c.detect_collect_best(1)[0].tobytes() == want_best.tobytes()
+        assert c.graph_launches == 6 and plain.graph_launches == 0
+    finally:
+        plain.close()
+        c.close()
+
+
 @pytest.mark.parametrize("wb", [False, True], ids=["plain", "whitebalance"])
 @pytest.mark.parametrize("w,h,n", [(320, 240, 3), (322, 241, 2), (1920, 1080, 1)])
 def test_graph_replay_equals_plain_enqueue(cascade, wb, w, h, n):

@@ -142,6 +142,10 @@ def simulate(frames, c, scheme):
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "lanes":
+        nframes = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+        lane_model(synth.mixed_batch(nframes, 320, 240, seed0=1234), load_cascade())
+        return
     nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (320, 240)
     c = load_cascade()
@@ -150,6 +154,67 @@ def main():
         act, issued = simulate(frames, c, scheme)
         print(f"{scheme:9s}: LDS cycles {act.sum():.3e} for {issued.sum():.3e} conflict-free -> conflict share {100 * (1 - issued.sum() / act.sum()):.1f} % of all cycles")
         print("    per stage cycles / conflict-free:", " ".join(f"{a / max(b, 1):.2f}" for a, b in zip(act, issued)), "| share of cycles:", " ".join(f"{100 * a / act.sum():.0f}%" for a in act))
+
+
+
+
+def lane_model(frames, c, scheme="strip4"):
+    """Wave passes of the stages after stage 0 as the kernel runs them (every wavefront walks its own queue in chunks of 64; once <= 64
+    windows are left in the tile all four wavefronts take a quarter of the stage's features for all of them = one pass in all) against
+    two alternatives: the queues balanced over the wavefronts whenever 64 < survivors <= 256, and two wavefronts per tile.
+    Weighted with the stage's sample count (~ its VALU + LDS instructions per pass)."""
+    pts = []
+    for j in range(NST):
+        st = c.stages[j]
+        n = 0
+        for k in range(int(st["count"])):
+            f = c.features[int(st["first"]) + k]
+            n += sum(1 for t in range(int(f["size"])) if f["pz"][t] >= 0) + sum(1 for t in range(int(f["size"])) if f["nz"][t] >= 0)
+        pts.append(n)
+    now = np.zeros(NST)
+    bal = np.zeros(NST)
+    two = np.zeros(NST)
+    ideal = np.zeros(NST)
+    for fr in frames:
+        levels, arena = ho.pyramid(fr)
+        for i in range(len(levels) - 12):
+            death = s1.survivors_for_scale(c, levels, arena, i)
+            if death is None:
+                continue
+            H2, W2 = death.shape
+            tw2, th2, ntx, nty = tile_shapes(W2, H2)
+            for ty in range(nty):
+                for tx in range(ntx):
+                    X0, Y0 = tx * tw2, ty * th2
+                    tw, th = min(tw2, W2 - X0), min(th2, H2 - Y0)
+                    d = death[Y0:Y0 + th, X0:X0 + tw]
+                    row, p, v0, v1 = enum_pairs(scheme, tw2, th, tw)
+                    npairs = len(row)
+                    nbat = -(-npairs // 32)
+                    for nw, acc in ((4, None), (2, two)):
+                        per = -(-nbat // nw)
+                        cnt = np.zeros((nw, NST + 1), dtype=np.int64)  # windows of wavefront w alive at the entry of stage j
+                        for wv in range(nw):
+                            lo, hi = min(wv * per * 32, npairs), min((wv * per + per) * 32, npairs)
+                            r_, p_ = row[lo:hi], p[lo:hi]
+                            for a, dx in ((v0[lo:hi], 0), (v1[lo:hi], 1)):
+                                dd = d[np.minimum(r_, th - 1), np.minimum(2 * p_ + dx, tw - 1)][a]
+                                for j in range(1, NST):
+                                    cnt[wv, j] += int((dd >= j).sum())
+                        for j in range(1, NST):
+                            T = int(cnt[:, j].sum())
+                            if T == 0:
+                                break
+                            if nw == 4:
+                                ideal[j] += pts[j] * T / 64.0
+                                passes = 1 if T <= 64 else int(sum(-(-int(x) // 64) for x in cnt[:, j]))
+                                now[j] += pts[j] * passes
+                                bal[j] += pts[j] * (1 if T <= 64 else (-(-T // 64) if T <= 256 else passes))
+                            else:
+                                acc[j] += pts[j] * (1 if T <= 64 else int(sum(-(-int(x) // 64) for x in cnt[:, j])))
+    print("stage:                ", " ".join(f"{j:8d}" for j in range(1, NST)))
+    for name, v in (("as it runs", now), ("balanced 64<T<=256", bal), ("two wavefronts/tile", two), ("full lanes", ideal)):
+        print(f"{name:22s}", " ".join(f"{x / 1e3:8.0f}" for x in v[1:]), f"  total {v.sum() / 1e3:.0f} k sample-passes ({100 * v.sum() / now.sum():.0f} %)")
 
 
 if __name__ == "__main__":

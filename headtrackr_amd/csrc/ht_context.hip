@@ -5,6 +5,7 @@
 //   geometry            ccv.js:110-147      (scale, scale_upto, level sizes, variant planes)
 //   hits -> seq rects   ccv.js:227-234,244-245
 //   grouping            ccv.js:34-107 (array_group), 249-332 (averaging, nested-rect filter)
+#include <sched.h>
 #include <algorithm>
 #include <cmath>
 #include <cstddef>
@@ -49,6 +50,25 @@ HtRange::~HtRange() {
 #include <mutex>
 static std::mutex g_live_mu;
 static std::vector<ht_ctx *> g_live;
+// ht_device_alloc buffers whose owning context was destroyed while ANOTHER live context still had frames bound inside them (a batch
+// host shares one frame buffer between its pipelined contexts): kept alive here and freed by the ht_destroy after which no live
+// context is bound inside them any more — never under a context that would read freed HBM on its next enqueue.
+struct HtOrphan {
+    void *p;
+    size_t bytes;
+    int device;
+    bool orphan;  // false: released by its own context's ht_destroy
+};
+static std::vector<HtOrphan> g_orphans;
+
+// g_live_mu held.  Reads the other contexts' d_frames without their lock: a context being re-bound concurrently with the destruction
+// or ht_device_free of the buffer it is bound to is a caller error (include/headtrackr_hip.h, "Lifetime of shared frame buffers").
+static bool bound_by_live_context(const ht_ctx *except, int device, const void *p, size_t bytes) {
+    const uint8_t *pb = static_cast<const uint8_t *>(p);
+    for (const ht_ctx *o : g_live)
+        if (o != except && o->device == device && o->d_frames && o->d_frames >= pb && o->d_frames < pb + bytes) return true;
+    return false;
+}
 
 static inline HtPostCfg post_cfg(const ht_ctx *c) { return HtPostCfg{c->interval, c->cw, c->ch}; }
 
@@ -57,8 +77,17 @@ static int ht_host_workers(const ht_ctx *c, int frames, uint32_t hits) {
     if (c->host_threads == 0) return 0;
     if (c->host_threads > 0) return c->host_threads;
     if (frames < 32 || hits < 256) return 0;  // a live feed's frame or two: the hand-off would cost more than the work
-    static const int hw = (int)std::thread::hardware_concurrency();
-    return std::max(0, std::min(7, hw / 2 - 1));
+    // auto: half of this process's share of the host cores — the cores its affinity mask allows, divided by the GPUs of the node (a
+    // one-process-per-GPU job runs one such pool per GPU: 8 ranks x 7 spinning workers must not pin 64 cores of a small host)
+    static const int share = [] {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        int cpus = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        int ngpu = 1;
+        if (hipGetDeviceCount(&ngpu) != hipSuccess || ngpu < 1) ngpu = 1;
+        return std::max(0, std::min(7, cpus / (2 * ngpu) - 1));
+    }();
+    return share;
 }
 
 
@@ -400,9 +429,25 @@ static void free_geometry(ht_ctx *c) {
 
 extern "C" void ht_destroy(ht_ctx *c) {
     if (!c) return;
+    std::vector<HtOrphan> release;  // buffers nobody is bound to any more: this context's own and orphans of earlier destroys
     {
         std::lock_guard<std::mutex> lk(g_live_mu);
         g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
+        for (auto &a : c->user_allocs) {
+            // same rule as ht_device_free: never free HBM under a live context that has frames bound inside it — the buffer outlives
+            // its owner as an orphan instead
+            if (bound_by_live_context(c, c->device, a.first, a.second)) g_orphans.push_back(HtOrphan{a.first, a.second, c->device, true});
+            else release.push_back(HtOrphan{a.first, a.second, c->device, false});
+        }
+        c->user_allocs.clear();
+        for (size_t i = 0; i < g_orphans.size();) {
+            if (!bound_by_live_context(nullptr, g_orphans[i].device, g_orphans[i].p, g_orphans[i].bytes)) {
+                release.push_back(g_orphans[i]);
+                g_orphans.erase(g_orphans.begin() + (long)i);
+            } else {
+                i++;
+            }
+        }
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -440,7 +485,14 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_cs_parts) (void)hipFree(c->d_cs_parts);
     if (c->d_cs_ctr) (void)hipFree(c->d_cs_ctr);
     if (c->d_gather) (void)hipFree(c->d_gather);
-    for (auto &a : c->user_allocs) (void)hipFree(a.first);
+    for (auto &a : release) {
+        if (a.orphan) {  // whatever a context that has meanwhile re-bound elsewhere still had enqueued against it has to be through
+            (void)hipSetDevice(a.device);
+            (void)hipDeviceSynchronize();
+        }
+        (void)hipFree(a.p);
+    }
+    (void)hipSetDevice(c->device);
     for (auto &t : c->timers)
         for (auto &p : t.pending) (void)hipEventDestroy(p.first), (void)hipEventDestroy(p.second);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -890,9 +942,8 @@ extern "C" ht_status ht_device_free(ht_ctx *c, void *p) {
     {   // a buffer that other contexts of this device have bound (ht_bind_frames_device: a batch host shares one frame buffer between
         // its pipelined contexts) is NOT freed under them: their next enqueue would read freed HBM.  Rebind or destroy them first.
         std::lock_guard<std::mutex> lk(g_live_mu);
-        for (ht_ctx *o : g_live)
-            if (o != c && o->device == c->device && o->d_frames && o->d_frames >= pb && o->d_frames < pb + it->second)
-                return ht_fail(c, HT_ERR_STATE, "ht_device_free: another live context still has frames bound inside this buffer (rebind or destroy it first)");
+        if (bound_by_live_context(c, c->device, pb, it->second))
+            return ht_fail(c, HT_ERR_STATE, "ht_device_free: another live context still has frames bound inside this buffer (rebind or destroy it first)");
     }
     if (c->d_frames && c->d_frames >= pb && c->d_frames < pb + it->second) {  // frames bound inside it
         c->d_frames = nullptr, c->nframes = 0;

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -202,35 +203,40 @@ public:
         static HtPool *p = new HtPool();  // never destroyed: worker threads must not be joined from a static destructor at exit
         return *p;
     }
-    // runs fn(begin, end) over [0, n) in chunks of `chunk` on up to `nthreads` workers + the calling thread; returns when all are done
+    // runs fn(begin, end) over [0, n) in chunks of `chunk` on up to `nthreads` workers + the calling thread; returns when all are done.
+    // The worker count may differ from batch to batch.  A generation and its participant count travel in ONE atomic word (`state_` =
+    // generation << 8 | participants): a worker decides from the very value that announced the batch whether it takes part, so a worker
+    // outside batch g can neither be counted in nor touch fn_ / n_ / chunk_ of batch g + 1 by accident, and every participant of batch g
+    // has acknowledged (pending_) before run() returns — nothing of a batch is read after its run() has returned.
     void run(int n, int chunk, int nthreads, const std::function<void(int, int)> &fn) {
         if (n <= 0) return;
-        nthreads = std::min(nthreads, (n + chunk - 1) / chunk - 1);
+        nthreads = std::min(std::min(nthreads, kMaxWorkers), (n + chunk - 1) / chunk - 1);
         if (nthreads <= 0) {
             fn(0, n);
             return;
         }
         std::lock_guard<std::mutex> user(user_mu_);  // one batch at a time
         ensure(nthreads);
-        fn_ = &fn, n_ = n, chunk_ = chunk;
+        fn_ = &fn, n_ = n, chunk_ = chunk;  // published by the release store of state_ below, read by participants only
         next_.store(0, std::memory_order_relaxed);
         pending_.store(nthreads, std::memory_order_relaxed);
-        active_ = nthreads;
+        const uint64_t gen = (state_.load(std::memory_order_relaxed) >> 8) + 1;
         {
             std::lock_guard<std::mutex> lk(mu_);
-            gen_.fetch_add(1, std::memory_order_release);
+            state_.store(gen << 8 | (uint64_t)nthreads, std::memory_order_release);
         }
         cv_.notify_all();
-        work();
+        work(&fn, n, chunk);
         while (pending_.load(std::memory_order_acquire) != 0) std::this_thread::yield();
     }
+    static constexpr int kMaxWorkers = 64;
 
 private:
-    void work() {
+    void work(const std::function<void(int, int)> *fn, int n, int chunk) {
         for (;;) {
-            const int b = next_.fetch_add(chunk_, std::memory_order_relaxed);
-            if (b >= n_) break;
-            (*fn_)(b, std::min(n_, b + chunk_));
+            const int b = next_.fetch_add(chunk, std::memory_order_relaxed);
+            if (b >= n) break;
+            (*fn)(b, std::min(n, b + chunk));
         }
     }
     void ensure(int nthreads) {
@@ -240,23 +246,36 @@ private:
             th_.back().detach();
         }
     }
+    static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#elif defined(__aarch64__)
+        asm volatile("yield" ::: "memory");
+#else
+        std::this_thread::yield();
+#endif
+    }
     void loop(int id) {
-        uint64_t seen = 0;
+        uint64_t seen = 0;  // generation this worker has dealt with
         for (;;) {
-            // spin for ~50 us worth of polls, then sleep on the condition variable
-            uint64_t g = gen_.load(std::memory_order_acquire);
-            for (int spin = 0; g == seen && spin < 20000; spin++) {
-                __builtin_ia32_pause();
-                g = gen_.load(std::memory_order_acquire);
+            // poll for ~50 us (a batch server collects a batch every ~0.25 ms), by the clock, then sleep on the condition variable
+            uint64_t st = state_.load(std::memory_order_acquire);
+            if ((st >> 8) == seen) {
+                const auto t_end = std::chrono::steady_clock::now() + std::chrono::microseconds(50);
+                for (int spin = 0; (st >> 8) == seen; spin++) {
+                    cpu_relax();
+                    st = state_.load(std::memory_order_acquire);
+                    if ((spin & 63) == 63 && std::chrono::steady_clock::now() >= t_end) break;
+                }
             }
-            if (g == seen) {
+            if ((st >> 8) == seen) {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen; });
-                g = gen_.load(std::memory_order_acquire);
+                cv_.wait(lk, [&] { return (state_.load(std::memory_order_acquire) >> 8) != seen; });
+                st = state_.load(std::memory_order_acquire);
             }
-            seen = g;
-            if (id < active_) {
-                work();
+            seen = st >> 8;
+            if (id < (int)(st & 0xff)) {  // participant of exactly this generation: run() waits for the acknowledgement below
+                work(fn_, n_, chunk_);
                 pending_.fetch_sub(1, std::memory_order_release);
             }
         }
@@ -264,10 +283,10 @@ private:
     std::mutex user_mu_, mu_;
     std::condition_variable cv_;
     std::vector<std::thread> th_;
-    std::atomic<uint64_t> gen_{0};
+    std::atomic<uint64_t> state_{0};  // generation << 8 | participating workers of that generation
     std::atomic<int> next_{0}, pending_{0};
     const std::function<void(int, int)> *fn_ = nullptr;
-    int n_ = 0, chunk_ = 1, active_ = 0;
+    int n_ = 0, chunk_ = 1;
 };
 
 // workers for a batch of `frames` frames holding `hits` raw hits: option host_threads, or (auto) up to 7 when the batch is worth it

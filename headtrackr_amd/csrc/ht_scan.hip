@@ -944,6 +944,9 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
             // written out: atomicAdd() is turned into a wave-aggregated add whose result is waited for on the spot (~2 us per window);
             // the compiler's own s_waitcnt vmcnt(k) stay correct with one more (older) operation in the in-order queue
             const uint32_t zero = 0u, one = 1u;
+            // `nxt` is NOT valid until the s_waitcnt vmcnt(0) asm below: nothing may read, copy or spill its register in between.  The
+            // compiler does not know that; tests/test_abi.py::test_deep_kernel_atomic_result_is_untouched_until_waited_for checks the
+            // code object of every build (the register is written by the atomic and first read after that s_waitcnt).
             asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(nxt) : "v"(zero), "v"(one), "s"(my_ctr) : "memory");
         }
         const HtQueueEntry ent = queue[e];
@@ -1429,7 +1432,10 @@ ht_status ht_launch_scan(ht_ctx *c, uint32_t flags) {
             // Measured with two batches in flight (round 4, tools/gpu_kernel_times.py): the kernel itself 0.038 -> 0.055 ms, the C2 step
             // 0.2514 -> 0.2440 ms (96 / 128 / 160 / 192 / 224 / 256 / 320 / 384 / 512 workgroups: 0.2528 / 0.2465 / 0.2445 / 0.2439 / 0.2470 /
             // 0.2456 / 0.2474 / 0.2480 / 0.2514), C4 unchanged; 8- and 16-wavefront workgroups have the same optimum.
-            hipLaunchKernelGGL(k_scan_deep_lds, dim3((uint32_t)c->deep_grid), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
+            // every one of the HT_DEEP_CTRS work counters needs a wavefront that draws from it (entry nwaves + 16 k + c is only ever
+            // handed out by counter c): a grid below 16 wavefronts (option deep_grid=1) would silently skip queue entries
+            const uint32_t deep_grid = std::max<uint32_t>((uint32_t)c->deep_grid, (HT_DEEP_CTRS + DEEPL_WAVES - 1) / DEEPL_WAVES);
+            hipLaunchKernelGGL(k_scan_deep_lds, dim3(deep_grid), dim3(64 * DEEPL_WAVES), lds, c->stream, c->d_arena, c->arena_stride, c->d_levels, c->next,
                                c->d_packed_feats, c->packed_count, c->packed_first, c->d_stages, (int)c->nstages, force_exact, c->d_queue, c->queue_capacity,
                                c->d_hits, c->hit_capacity, c->d_counters, stats);
         } else

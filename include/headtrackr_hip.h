@@ -122,6 +122,10 @@ typedef struct ht_kernel_time { /* per-kernel device time of the last ht_detect_
 /* Creates a context on cfg->device holding the cascade (an "HTCB" blob, see headtrackr_amd/js/cascade_pack.js)
  * = the `cascade` argument of ccv.detect_objects (ccv.js:109; data: cascade.js:19). */
 ht_status ht_create(const ht_config *cfg, const void *cascade_blob, size_t cascade_len, ht_ctx **out);
+/* Lifetime of shared frame buffers: a buffer of ht_device_alloc that OTHER live contexts still have frames bound inside
+ * (ht_bind_frames_device) is not freed by its owner's ht_destroy — it stays alive and is released by the ht_destroy after which no
+ * live context is bound inside it.  The recommended order is still binders first, owner last.  A context must not be re-bound
+ * concurrently (another thread) with the destruction / ht_device_free of the buffer it is bound to. */
 void ht_destroy(ht_ctx *ctx);
 /* Message of the last failure on ctx (ctx == NULL: last failure of ht_create on this thread). Never NULL. */
 const char *ht_last_error(const ht_ctx *ctx);

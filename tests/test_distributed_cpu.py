@@ -102,6 +102,8 @@ def test_bench_gpus_n_launches_n_ranks():
     assert line["allgather_verified"] is True and line["steps"] == 4 and line["rounds"] >= 3
     assert line["ms_per_step_min"] <= line["ms_per_step"] <= line["ms_per_step_max"]
     assert line["config"]["frames_total"] == 2 * line["config"]["frames_per_gpu"]
+    assert line["rank_ms_per_step_min"] <= line["rank_ms_per_step_max"] and line["data"] == "stub"
+    assert len(r.stdout.strip().splitlines()[-1]) < 2000  # the one line stays a headline (benchlib/line.py)
 
 
 def test_bench_refuses_to_mislabel_the_gpu_count():

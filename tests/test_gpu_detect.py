@@ -151,6 +151,66 @@ def test_mixed_batch_hits_vs_oracle(ctx, cascade, mode):
     assert hits2.tobytes() == hits.tobytes()
 
 
+@pytest.mark.parametrize("grid", [1, 2, 3, 17])
+def test_deep_kernel_grid_option_never_loses_queue_entries(cascade, grid):
+    """k_scan_deep_lds hands queue entries out through 16 work counters, counter c serving the entries
+    nwaves + 16 k + c — with option deep_grid=1 (12 wavefronts) counters 12..15 had no wavefront and their entries were silently
+    skipped.  The launch now keeps the grid at >= 16 wavefronts; every grid size returns the oracle's hits."""
+    w, h, n = 320, 240, 24
+    frames = synth.mixed_batch(n, w, h, seed0=4321)
+    c = Context(options=f"deep_grid={grid}")
+    try:
+        hits, counts = c.detect_raw(frames)
+        ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(n)])
+        assert len(ref) > 50
+        assert_hits_equal(hits, ref)
+    finally:
+        c.close()
+
+
+def test_destroying_the_owner_of_a_shared_frame_buffer_keeps_it_alive_for_its_binders(cascade):
+    """ht_destroy of the context that ht_device_alloc'ed a frame buffer used to free it under the other contexts
+    bound inside it (dangling d_frames + graphs keyed on it).  The buffer now outlives its owner until no live context is bound to
+    it: the binder still detects the same hits after the owner is gone — from fresh launches and from its replayed graph."""
+    import ctypes as C
+
+    from headtrackr_amd import native
+
+    L = native.lib()
+    w, h, n = 320, 240, 8
+    frames = np.ascontiguousarray(synth.mixed_batch(n, w, h, seed0=99))
+    ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(n)])
+    owner, binder = Context(), Context()
+    try:
+        p = C.c_void_p()
+        assert L.ht_device_alloc(owner._h, frames.nbytes, C.byref(p)) == 0
+        assert L.ht_device_upload(owner._h, p, frames.ctypes.data, frames.nbytes) == 0
+        for cx in (owner, binder):
+            cx.set_geometry(w, h, n)
+            cx.bind_device(p.value, n)
+        for _ in range(4):  # the third enqueue onwards replays the captured graph
+            binder.detect_enqueue(0)
+            hits, _ = binder.detect_collect()
+        assert_hits_equal(hits, ref)
+        assert L.ht_device_free(owner._h, p) != 0  # refused while the binder is bound
+        owner.close()  # the owner goes first: the buffer must stay valid
+        junk = [Context() for _ in range(2)]  # allocations that would reuse freed HBM
+        for j in junk:
+            j.set_geometry(w, h, n)
+            j.upload(frames[::-1].copy())
+            j.detect_enqueue(0)
+            j.detect_collect()
+        for _ in range(3):
+            binder.detect_enqueue(0)
+            hits, _ = binder.detect_collect()
+            assert_hits_equal(hits, ref)
+        for j in junk:
+            j.close()
+    finally:
+        owner.close()
+        binder.close()  # releases the orphaned buffer
+
+
 def test_gray_in_r_entry(ctx, cascade):
     """HT_INPUT_GRAY_IN_R == calling ccv.detect_objects on an already gray canvas"""
     frame = synth.face_frame(320, 240, [(100, 60, 96)])

@@ -75,11 +75,12 @@ def test_c4_batch_shape_every_frame_vs_oracle(cascade):
         c.close()
 
 
-@pytest.mark.parametrize("rank", [0, 1])
+@pytest.mark.parametrize("rank", list(range(8)))
 def test_c4_bench_frames_all_128_distinct_vs_oracle(cascade, rank):
-    """The frames bench.py TIMES at C4: all 128 distinct 1280x720 frames of a rank's batch (seed 1234 + 1000 * rank; ranks 0 and 1
-    here — rank r > 0 of an N-GPU run times frames no other test has seen), in one batch like the bench: every frame's raw hits
-    (indices + binary64 confidence bits), the per-stage window counts and the best face per frame == the oracle's."""
+    """The frames bench.py TIMES at C4: all 128 distinct 1280x720 frames of a rank's batch (seed 1234 + 1000 * rank) for EVERY rank
+    of the 8-GPU run of BASELINE.json configs[3] — rank r > 0 times frames no other test has seen —, in one batch like the bench:
+    every frame's raw hits (indices + binary64 confidence bits), the per-stage window counts and the best face per frame == the
+    oracle's."""
     w, h, n = 1280, 720, 128
     frames = synth.mixed_batch(n, w, h, seed0=1234 + 1000 * rank)
     stage_ref = np.zeros(cascade.count + 1, dtype=np.int64)

@@ -77,18 +77,27 @@ def test_group_rects_nan_and_degenerate_widths():
 # and byte-identical with 0, 3 and 7 workers.
 
 
-@pytest.fixture(scope="module")
-def harness(tmp_path_factory):
+def _build_harness(tmp_path_factory, name, sanitize):
     import os
     import subprocess
 
     from conftest import ROOT
 
-    exe = str(tmp_path_factory.mktemp("hostpost") / "hostpost_harness")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-pthread",
+    exe = str(tmp_path_factory.mktemp(name) / "hostpost_harness")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", f"-fsanitize={sanitize}", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-pthread",
                            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "headtrackr_amd", "csrc"),
                            os.path.join(ROOT, "tests", "host", "hostpost_harness.cc"), "-o", exe])
     return exe
+
+
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    return _build_harness(tmp_path_factory, "hostpost", "address,undefined")
+
+
+@pytest.fixture(scope="module")
+def harness_tsan(tmp_path_factory):
+    return _build_harness(tmp_path_factory, "hostpost_tsan", "thread")
 
 
 def _raw_hits(rng, nfr, faces_per_frame, strays):
@@ -120,7 +129,8 @@ def _run_harness(exe, tmp_path, raw, nfr, min_neighbors, workers, repeat=1):
         fh.write(np.array([nfr, len(raw), min_neighbors, 5], dtype=np.int32).tobytes())
         fh.write(np.ascontiguousarray(raw).tobytes())
     r = subprocess.run([exe, fin, fout, str(workers), str(repeat)], capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1"))
+                       env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="print_stacktrace=1",
+                                TSAN_OPTIONS="halt_on_error=1:exitcode=66"))
     assert r.returncode == 0, r.stderr[-3000:]
     blob = open(fout, "rb").read()
     ok = int(np.frombuffer(blob[:4], dtype=np.uint32)[0])
@@ -172,3 +182,27 @@ def test_host_pass_rejects_a_frame_index_outside_the_batch(harness, tmp_path):
     raw["frame"][len(raw) // 2] = 8
     ok, *_ = _run_harness(harness, tmp_path, raw, 8, 1, 3)
     assert ok == 0
+
+
+def test_pool_with_a_worker_count_that_changes_every_batch_is_race_free(harness_tsan, harness, tmp_path):
+    """HtPool decided a worker's participation from `active_` read AFTER the generation it belonged to — a worker
+    outside batch g (id >= active) that was preempted there could join batch g + 1 uncounted, decrement pending_ twice, and run()
+    could return while it was still inside fn.  Now {generation, participants} travel in one atomic word.  The product varies the
+    worker count per batch (ht_host_workers), so this runs 60 batches with the count cycling 7, 3, 7, 1, 5, 0, 2 inside ONE process
+    — under ThreadSanitizer (no data race, no use of a dead batch's lambda) and under ASan — and compares with the oracle."""
+    from oracle import ht_oracle as ho
+
+    rng = np.random.default_rng(77)
+    nfr = 96
+    raw = _raw_hits(rng, nfr, 2, 3)
+    want = None
+    for exe in (harness_tsan, harness):
+        ok, hits, counts, best = _run_harness(exe, tmp_path, raw, nfr, 1, "7,3,7,1,5,0,2", repeat=60)
+        assert ok == 1
+        if want is None:
+            want = (hits.copy(), counts.copy(), best.copy())
+            ok0, h0, c0, b0 = _run_harness(harness, tmp_path, raw, nfr, 1, 0)
+            assert ok0 == 1
+            assert h0.tobytes() == hits.tobytes() and c0.tobytes() == counts.tobytes() and b0.tobytes() == best.tobytes()
+        else:
+            assert hits.tobytes() == want[0].tobytes() and counts.tobytes() == want[1].tobytes() and best.tobytes() == want[2].tobytes()

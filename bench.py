@@ -69,6 +69,7 @@ def parse():
                     help="c5: live feeds per GPU; 8 on one GPU is the N = 1 point of BASELINE.json configs[4]")
     ap.add_argument("--rounds", type=int, default=0,
                     help="repetitions of the K-step timed block (median reported); 0 = auto: ~0.4 s, 3..25 rounds")
+    ap.add_argument("--options", default="", help="ht_config.options of every context (result-preserving schedule A/B)")
     ap.add_argument("--force-launcher", action="store_true",
                     help="start the rank(s) through torch.distributed.run even for --gpus 1 (RCCL init + all-gather)")
     a = ap.parse_args()

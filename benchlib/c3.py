@@ -45,7 +45,7 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
     depth = a.pipeline if a.pipeline > 0 else 3
     ctxs = []
     for _ in range(depth):
-        cx = Context(device=local)
+        cx = Context(device=local, options=a.options or None)
         cx.set_geometry(W, H, nf)
         cx.bind_device(dev_vers[0].data_ptr(), nf, W * H * 4)
         cx.camshift_reserve(nf)

@@ -45,7 +45,7 @@ def stream_bench(env, a, feeds=1, steps=300, warm_cycles=1, cpu_seconds=0.0):
         for f in range(K):
             hv[k, f] = uniq[synth.stream_frame_index(k, f, NUNIQ)]
     dev = host.cuda()  # the same steps resident in HBM (NUNIQ x K x 8.3 MB)
-    ctx = Context(device=local)
+    ctx = Context(device=local, options=a.options or None)
     ctx.set_geometry(W, H, K)
     ctx.camshift_reserve(K)
     sbytes = K * fbytes

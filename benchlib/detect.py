@@ -47,7 +47,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     depth = a.pipeline if a.pipeline > 0 else (3 if nf * arena_estimate(W, H) <= 256 * 1024 * 1024 else 2)
     ctxs = []
     for _ in range(depth):
-        cx = Context(device=local)
+        cx = Context(device=local, options=a.options or None)
         cx.set_geometry(W, H, nf)
         cx.bind_device(dev.data_ptr(), nf, W * H * 4)
         ctxs.append(cx)

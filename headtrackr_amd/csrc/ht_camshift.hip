@@ -17,6 +17,7 @@
 // thread-to-pixel assignment and a fixed reduction tree (deterministic); the summation ORDER differs from the
 // reference's column-major scalar loop, so results are equal up to rounding in the last bits of xc/yc — the
 // acceptance bound of BASELINE.json (+-1 px, +-0.5 deg) covers the rare truncation flips this can cause.
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -400,7 +401,7 @@ __device__ __forceinline__ CsRegion cs_cache_region(const uint32_t *__restrict__
 // `moments(x, y, w, h)` computes camshift.Moments (all six sums) over the window for the whole workgroup (every thread gets the same Mom).
 template <typename MOMENTS>
 __device__ __forceinline__ void meanshift_body(int W, int H, const int *s_sw, HtCsState &st, int calc_angles, int max_it, ht_cs_trackobj *__restrict__ out_s,
-                                               unsigned long long *stamps, bool writer, MOMENTS moments) {
+                                               unsigned long long *stamps, bool writer, MOMENTS moments, uint32_t *done_flag = nullptr, uint32_t done_seq = 0u) {
     int swx = uni(s_sw[0]), swy = uni(s_sw[1]);
     int n_stamp = 4;
     (void)n_stamp;
@@ -468,6 +469,10 @@ __device__ __forceinline__ void meanshift_body(int W, int H, const int *s_sw, Ht
         o.x = tx, o.y = ty, o.width = width, o.height = height, o.angle = angle;
         o.sw_x = swx, o.sw_y = swy, o.sw_width = nsww, o.sw_height = nswh;
         *out_s = o;
+    }
+    if (done_flag) {  // enqueue-only call: the host polls this word of the pinned slot instead of waiting for an event
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // system scope: the track object above is visible before the flag
+        __hip_atomic_store(done_flag, done_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -681,20 +686,26 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFusedArgs a
 // ---- few large streams: a CLUSTER of workgroups per stream ---------------------------------------------------------------
 // One workgroup streams a window at one CU's memory rate: a 360 x 360 search window of a 1080p feed (130 k pixels, 0.5 MB per
 // pass) took ~30 us per pass, 146 us per track() call.  Here G workgroups share every pass (rows interleaved over all their
-// wavefronts), publish their six partial sums with agent-scope stores, arrive on a per-stream counter (zeroed by the host before
-// the launch) and read everybody's partials back once the counter shows all G arrivals — a counter barrier, ~3 us per
-// iteration (MI355X_MICROARCH.md price list), no agent-scope fences (payload and flag are sc1 / atomic both sides).  Every
-// workgroup sums the G partials in the same order, so all of them take identical mean-shift decisions; workgroup 0 writes the
-// state.  The grid (streams x G <= 256 workgroups) is always co-resident: the spin cannot starve a workgroup that has not started.
+// wavefronts) and publish their six partial sums with agent-scope stores into the pass's exchange slot, whose entries k_cs_lut
+// marked "not written yet" (a NaN no sum can be): every workgroup polls the G x 6 entries, one thread per entry, until the mark is
+// gone — the value that ends the wait is the partial sum itself (round 5; until then: store, drain, arrive on a counter, poll the
+// counter, read the partials = three dependent L2 round trips, ~3 us per pass).  No agent-scope fences: every payload word is an
+// sc1 store on one side and an sc1 load on the other.  Every workgroup sums the G partials in the same order, so all of them take
+// identical mean-shift decisions; workgroup 0 writes the state.  The grid (streams x G <= 256 workgroups) is always co-resident: the spin cannot starve a workgroup that has not started.
 constexpr int CL_NT = 512, CL_MAXG = 32, CL_SLOTS = 12;  // <= 11 moment passes per call (camshift.js:284-306)
+// "not written yet" mark of an exchange entry: a NaN no moment sum can be (the sums are finite and >= 0)
+constexpr unsigned long long CL_UNWRITTEN = 0xFFF8C0DEC0DE0001ull;
 
 // weight LUT of every stream from its chunk histograms (getWeights, camshift.js:314-330): grid (64, streams) x 512 threads;
 // a block owns 64 bins, its 8 wavefronts each sum every 8th chunk (a single 1080p stream has 127 chunk histograms = 2 MB)
 __global__ __launch_bounds__(512) void k_cs_lut(const uint32_t *__restrict__ hist, int nchunks, const HtCsState *__restrict__ states, int first,
-                                                double *__restrict__ lut, unsigned long long *__restrict__ cluster_ctr) {
+                                                double *__restrict__ lut, unsigned long long *__restrict__ cluster_parts) {
     __shared__ uint32_t part[8][64];
     const int s = blockIdx.y, lane = threadIdx.x & 63, grp = threadIdx.x >> 6, bin = blockIdx.x * 64 + lane;
-    if (blockIdx.x == 0 && threadIdx.x == 0) cluster_ctr[s] = 0ull;  // the stream's arrival counter of the cluster launch that follows (was a memset of its own)
+    {   // the stream's exchange slots of the cluster launch that follows: every entry "not written yet" (was a memset of its own)
+        const uint32_t i = blockIdx.x * 512u + threadIdx.x;
+        if (i < (uint32_t)(CL_SLOTS * CL_MAXG * 6)) cluster_parts[(size_t)s * CL_SLOTS * CL_MAXG * 6 + i] = CL_UNWRITTEN;
+    }
     const uint32_t *cur = hist + (size_t)s * nchunks * 4096 + bin;
     uint32_t ch = 0;
 #pragma unroll 4
@@ -714,15 +725,14 @@ __global__ __launch_bounds__(512) void k_cs_lut(const uint32_t *__restrict__ his
     }
 }
 
-// The barrier is a spin on an agent-scope counter, so it is BOUNDED: a workgroup that has waited `budget` shader-clock cycles (a
-// quarter of a second by default, against ~3 us for a healthy barrier) raises the context's error word and stops waiting — at this and
-// every later barrier of the call (s_timeout is sticky).  The host reports HT_ERR_STATE with the next result read-back; the stream's
+// The wait is a spin on agent-scope loads, so it is BOUNDED: a thread that has waited `budget` shader-clock cycles (a quarter of a
+// second by default, against ~1-2 us for a healthy exchange) raises the context's error word and its workgroup stops waiting — at this
+// and every later exchange of the call (s_timeout is sticky).  The host reports HT_ERR_STATE with the next result read-back; the stream's
 // state is then garbage for this call, but nothing hangs.  Co-residency (the premise of the spin) is arranged by the host: one cluster
 // launch in flight per device and process, grid <= one workgroup per CU (launch_track).
-// Ordering: payload stores are sc1 (agent scope) and drained with s_waitcnt vmcnt(0) before the arrival atomic is issued; reads of the
-// payload are sc1 loads issued after the counter was observed.  That is the gfx9 memory model; ht_create refuses any other arch.
+// Ordering: an entry is ONE 8-byte word, written by an sc1 (agent-scope) store and read by sc1 loads — single-copy atomic, nothing else
+// depends on it.  That is the gfx9 memory model; ht_create refuses any other arch.
 struct ClusterSync {
-    unsigned long long *counter;
     uint32_t *err;
     uint32_t *err_host;  // pinned host word (plain system-scope store of 1): an enqueue-only call's host side reads it without a copy
     long long budget;
@@ -731,7 +741,6 @@ struct ClusterSync {
 template <bool SECOND>
 __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img, int W, const double *lut, int x, int y, int w, int h, double (*red)[CL_NT / 64],
                                                double *s_part, int g, int G, double *__restrict__ parts, const ClusterSync &sync, int slot) {
-    unsigned long long *const counter = sync.counter;
     constexpr int NW = CL_NT / 64, nv = SECOND ? 6 : 3;
     Mom m = {0, 0, 0, 0, 0, 0};
     const int ww = w - x, hh = h - y;
@@ -773,35 +782,39 @@ __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img,
         if (lane == 0) red[k][wave] = sum;
     }
     __syncthreads();
-    // this workgroup's partial sums -> its slot of the exchange buffer; arrive; wait for all G; read everybody's
-    double *slot_parts = parts + (size_t)slot * CL_MAXG * 6;
+    // this workgroup's partial sums -> its entries of the pass's exchange slot (agent-scope stores, fire and forget); then every entry
+    // of the slot is polled by a thread of its own until it no longer holds the "not written yet" mark k_cs_lut left there: the value
+    // that ends the wait IS the partial sum — no arrival counter, no drain of the stores, no second read (a pass used to be
+    // store -> s_waitcnt -> atomic add -> poll the counter -> read the G partials: three dependent round trips through L2).
+    unsigned long long *slot_parts = reinterpret_cast<unsigned long long *>(parts) + (size_t)slot * CL_MAXG * 6;
     if (threadIdx.x < nv) {
         double sum = 0.0;
 #pragma unroll
         for (int q = 0; q < NW; q++) sum += red[threadIdx.x][q];
-        __hip_atomic_store(&slot_parts[g * 6 + threadIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&slot_parts[g * 6 + threadIdx.x], (unsigned long long)__double_as_longlong(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (threadIdx.x < 64) {  // wavefront 0 issued the stores: drain them, then one arrival per workgroup
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) {
-            __hip_atomic_fetch_add(counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned long long target = (unsigned long long)G * (unsigned long long)(slot + 1);
-            if (!*sync.s_timeout) {
+    if ((int)threadIdx.x < G * 6) {
+        unsigned long long bits = 0ull;  // +0.0 for the entries a first-moment pass does not use
+        if ((int)(threadIdx.x % 6u) < nv) {
+            bits = __hip_atomic_load(&slot_parts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bits == CL_UNWRITTEN && !*sync.s_timeout) {
                 const long long t0 = (long long)__builtin_readcyclecounter();
-                while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                for (;;) {
+                    __builtin_amdgcn_s_sleep(1);
+                    bits = __hip_atomic_load(&slot_parts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (bits != CL_UNWRITTEN) break;
                     if ((long long)__builtin_readcyclecounter() - t0 > sync.budget) {  // bounded spin: give up, flag it, never wait again
                         *sync.s_timeout = 1;
                         atomicOr(sync.err, 1u);
                         if (sync.err_host) __hip_atomic_store(sync.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
-                    __builtin_amdgcn_s_sleep(2);
                 }
             }
+            if (bits == CL_UNWRITTEN) bits = 0ull;  // timed out: the call's result is undefined (reported), but it stays a number
         }
+        s_part[threadIdx.x] = __longlong_as_double((long long)bits);
     }
-    __syncthreads();
-    if ((int)threadIdx.x < G * 6) s_part[threadIdx.x] = __hip_atomic_load(&slot_parts[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     {  // lane k of every wavefront adds moment k's G partials in the fixed order q = 0 .. G-1: every workgroup of the cluster gets the same bits
         double sacc = 0.0;
@@ -817,9 +830,9 @@ __device__ __forceinline__ Mom cluster_moments(const uint32_t *__restrict__ img,
 
 __global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *__restrict__ frames, size_t frame_stride, int W, int H, const double *__restrict__ lut_g,
                                                                 HtCsState *__restrict__ states, int first, int calc_angles, int max_it, int G,
-                                                                double *__restrict__ parts, unsigned long long *__restrict__ counters,
+                                                                double *__restrict__ parts,
                                                                 uint32_t *__restrict__ err, uint32_t *__restrict__ err_host, long long budget,
-                                                                ht_cs_trackobj *__restrict__ out) {
+                                                                ht_cs_trackobj *__restrict__ out, uint32_t *__restrict__ done_flags, uint32_t done_seq) {
     __shared__ double lut[4096];
     __shared__ double red[6][CL_NT / 64];
     __shared__ double s_part[CL_MAXG * 6];
@@ -836,12 +849,12 @@ __global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *_
     if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
     __syncthreads();
     double *my_parts = parts + (size_t)s * CL_SLOTS * CL_MAXG * 6;
-    const ClusterSync sync = {counters + s, err, err_host, budget, &s_timeout};
+    const ClusterSync sync = {err, err_host, budget, &s_timeout};
     int slot = 0;
     meanshift_body(W, H, s_sw, st, calc_angles, max_it, out ? out + s : nullptr, nullptr, g == 0, [&](int x, int y, int w, int h) {
         const int sl = slot++;
         return cluster_moments<true>(img, W, lut, x, y, w, h, red, s_part, g, G, my_parts, sync, sl);
-    });
+    }, done_flags ? done_flags + s : nullptr, done_seq);
 }
 
 }  // namespace
@@ -853,13 +866,33 @@ __global__ __launch_bounds__(CL_NT) void k_cs_meanshift_cluster(const uint8_t *_
 namespace {
 struct ClusterGate {
     std::mutex mu;
-    std::map<int, hipEvent_t> last;  // device -> event recorded after the most recent cluster launch
+    struct Dev {
+        hipEvent_t last = nullptr;            // recorded after the most recent cluster launch (only while `multi`)
+        std::vector<const ht_ctx *> users;    // contexts that have launched a cluster grid on this device
+        bool multi = false;                   // more than one user: every launch waits for `last` and records it
+    };
+    std::map<int, Dev> dev;
 };
 ClusterGate &cluster_gate() {
     static ClusterGate g;
     return g;
 }
 
+}  // namespace
+// ht_destroy: the context stops counting as a user of its device's cluster gate (its stream has been synchronised)
+void ht_cluster_gate_forget(const ht_ctx *c) {
+    ClusterGate &gate = cluster_gate();
+    std::lock_guard<std::mutex> lk(gate.mu);
+    auto it = gate.dev.find(c->device);
+    if (it == gate.dev.end()) return;
+    auto &u = it->second.users;
+    u.erase(std::remove(u.begin(), u.end(), c), u.end());
+    if (u.size() <= 1 && it->second.multi) {
+        // back to one user: its recorded grids are ordered by its own stream from here on
+        it->second.multi = false;
+    }
+}
+namespace {
 // fetched with every result read-back: a cluster barrier that ran out of its cycle budget surfaces as a status code
 ht_status cs_check_err(ht_ctx *c, const char *where) {
     const bool direct = c->h_cs_err_direct && __atomic_load_n(c->h_cs_err_direct, __ATOMIC_ACQUIRE) != 0;
@@ -882,14 +915,12 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
     uint32_t *nhist = nullptr, *nerr = c->d_cs_err, *herr = c->h_cs_err;
     ht_cs_trackobj *nout = nullptr;
     double *nlut = nullptr, *nparts = nullptr;
-    unsigned long long *nctr = nullptr;
     bool ok = hipMalloc(&ns, sizeof(HtCsState) * (size_t)nstreams) == hipSuccess &&
               hipMalloc(&nhist, sizeof(uint32_t) * 4096 * hist_max_chunks(nstreams) * (size_t)nstreams) == hipSuccess &&
               hipMalloc(&nout, sizeof(ht_cs_trackobj) * (size_t)nstreams) == hipSuccess &&
-              // cluster mean-shift (few large streams): per stream a LUT, CL_SLOTS x CL_MAXG partial-sum slots and an arrival counter
+              // cluster mean-shift (few large streams): per stream a LUT and CL_SLOTS x CL_MAXG partial-sum slots
               hipMalloc(&nlut, sizeof(double) * 4096 * (size_t)ncl) == hipSuccess &&
-              hipMalloc(&nparts, sizeof(double) * CL_SLOTS * CL_MAXG * 6 * (size_t)ncl) == hipSuccess &&
-              hipMalloc(&nctr, sizeof(unsigned long long) * (size_t)ncl) == hipSuccess;
+              hipMalloc(&nparts, sizeof(double) * CL_SLOTS * CL_MAXG * 6 * (size_t)ncl) == hipSuccess;
     if (ok && !nerr) ok = hipMalloc(&nerr, sizeof(uint32_t)) == hipSuccess && hipMemset(nerr, 0, sizeof(uint32_t)) == hipSuccess;
     if (ok && !herr) {
         ok = hipHostMalloc(reinterpret_cast<void **>(&herr), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess;
@@ -905,7 +936,6 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
         if (nout) (void)hipFree(nout);
         if (nlut) (void)hipFree(nlut);
         if (nparts) (void)hipFree(nparts);
-        if (nctr) (void)hipFree(nctr);
         if (nerr && nerr != c->d_cs_err) (void)hipFree(nerr);
         if (herr && herr != c->h_cs_err) (void)hipHostFree(herr);
         return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_reserve: allocation failed (the previous reservation is unchanged)");
@@ -915,10 +945,10 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
     if (c->d_cs_lut) (void)hipFree(c->d_cs_lut);
     if (c->d_cs_parts) (void)hipFree(c->d_cs_parts);
-    if (c->d_cs_ctr) (void)hipFree(c->d_cs_ctr);
-    c->d_cs = ns, c->d_cs_hist = nhist, c->d_cs_out = nout, c->d_cs_lut = nlut, c->d_cs_parts = nparts, c->d_cs_ctr = nctr;
+    c->d_cs = ns, c->d_cs_hist = nhist, c->d_cs_out = nout, c->d_cs_lut = nlut, c->d_cs_parts = nparts;
     c->d_cs_err = nerr, c->h_cs_err = herr;
     c->cs_last_n = c->cs_last_chunks = 0;  // the debug histogram buffer is new
+    c->cs_last_hist = nullptr;
     c->cs_streams = nstreams;
     // result ring of the enqueue-only track calls (the stream was synchronised above: no slot is in use; uncollected results are dropped)
     c->cs_ring_head = c->cs_ring_count = 0;
@@ -935,6 +965,13 @@ extern "C" ht_status ht_camshift_reserve(ht_ctx *c, int32_t nstreams) {
             return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_reserve: hipHostMalloc failed");
         }
         if (!sl.ev && hipEventCreateWithFlags(&sl.ev, hipEventDisableTiming) != hipSuccess) return ht_fail(c, HT_ERR_HIP, "ht_camshift_reserve: hipEventCreate failed");
+        if (sl.h_flag) (void)hipHostFree(sl.h_flag);
+        sl.h_flag = nullptr, sl.seq = 0;
+        if (hipHostMalloc(reinterpret_cast<void **>(&sl.h_flag), sizeof(uint32_t) * (size_t)nstreams, hipHostMallocDefault) != hipSuccess) {
+            c->cs_ring_streams = 0;
+            return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_reserve: hipHostMalloc failed");
+        }
+        std::memset(sl.h_flag, 0, sizeof(uint32_t) * (size_t)nstreams);
     }
     c->cs_ring_streams = nstreams;
     return HT_OK;
@@ -967,8 +1004,10 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
 }
 
 // one track() call of streams [first, first + n) on frames[0..n): histogram pass + mean-shift, results to d_out[0..n)
+// done_flags (pinned, n words) / done_seq: completion marks for an enqueue-only call — written by the cluster kernel if that path is
+// taken (*flags_used = true), otherwise the caller records its event.
 static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_stride, int32_t first, int32_t n, int32_t calc_angles,
-                              ht_cs_trackobj *d_out) {
+                              ht_cs_trackobj *d_out, uint32_t *done_flags = nullptr, uint32_t done_seq = 0u, bool *flags_used = nullptr) {
     const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
     if (!c->cs_attr_set) {  // the cached search region needs more than the default 64 KB of LDS per workgroup (per context = per device)
         HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
@@ -988,41 +1027,61 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
         hipLaunchKernelGGL(k_cs_track_fused<false>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, ka);
         HT_HIP(c, hipGetLastError());
         c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;
+        c->cs_last_hist = c->d_cs_hist;
         return HT_OK;
     }
     uint32_t chunk_px, nchunks;
     hist_chunks(npix, hist_max_chunks(c->cs_streams), &chunk_px, &nchunks);  // buffer sized for cs_streams x that many chunks
-    {
-        HtProfScope ps(c, "cs_hist");
-        hipLaunchKernelGGL(k_cs_hist, dim3(nchunks, n), dim3(HIST_NT), 0, c->stream, frames, frame_stride, npix, chunk_px, c->d_cs_hist);
-        HT_HIP(c, hipGetLastError());
-    }
     // a few large frames: G workgroups per stream share every moment pass (k_cs_meanshift_cluster); otherwise one workgroup per stream
     // cluster size: the grid never exceeds one workgroup per CU of THIS device, so it is co-resident whatever else is resident
     // (a CU has room for four of these workgroups); fewer than 4 workgroups per stream are not worth the barriers
     const int G = std::min(CL_MAXG, c->num_cus / std::max(n, 1));
-    if (c->cs_cluster && n <= 64 && G >= 4 && npix >= c->cs_cluster_min_px && c->dbg_cs_iters > 0) {
-        {
-            HtProfScope ps(c, "cs_lut");
-            hipLaunchKernelGGL(k_cs_lut, dim3(64, n), dim3(512), 0, c->stream, c->d_cs_hist, (int)nchunks, c->d_cs, first, c->d_cs_lut, c->d_cs_ctr);
-            HT_HIP(c, hipGetLastError());
-        }
+    const bool cluster = c->cs_cluster && n <= 64 && G >= 4 && npix >= c->cs_cluster_min_px && c->dbg_cs_iters > 0;
+    uint32_t *hist = c->d_cs_hist;
+    double *lut = c->d_cs_lut;
+    {
+        HtProfScope ps(c, "cs_hist");
+        hipLaunchKernelGGL(k_cs_hist, dim3(nchunks, n), dim3(HIST_NT), 0, c->stream, frames, frame_stride, npix, chunk_px, hist);
+        HT_HIP(c, hipGetLastError());
+    }
+    if (cluster) {
+        HtProfScope ps(c, "cs_lut");
+        hipLaunchKernelGGL(k_cs_lut, dim3(64, n), dim3(512), 0, c->stream, hist, (int)nchunks, c->d_cs, first, lut,
+                           reinterpret_cast<unsigned long long *>(c->d_cs_parts));
+        HT_HIP(c, hipGetLastError());
+    }
+    if (cluster) {
         HtProfScope ps(c, "cs_meanshift");
+        if (flags_used) *flags_used = done_flags != nullptr;
         ClusterGate &gate = cluster_gate();
         std::lock_guard<std::mutex> lk(gate.mu);
-        hipEvent_t &ev = gate.last[c->device];
-        if (!ev) HT_HIP(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        else HT_HIP(c, hipStreamWaitEvent(c->stream, ev, 0));  // the previous cluster grid on this device (any context) has drained
-        hipLaunchKernelGGL(k_cs_meanshift_cluster, dim3(n * G), dim3(CL_NT), 0, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_lut, c->d_cs, first,
-                           calc_angles, c->dbg_cs_iters, G, c->d_cs_parts, c->d_cs_ctr, c->d_cs_err, c->h_cs_err_direct, (long long)c->cs_barrier_budget, d_out);
+        ClusterGate::Dev &gd = gate.dev[c->device];
+        if (std::find(gd.users.begin(), gd.users.end(), c) == gd.users.end()) {
+            // A single context's cluster grids are ordered by its own stream: no event traffic (a record is a barrier packet of its own
+            // between this step's last and the next step's first kernel).  When a second context of the device starts using the
+            // cluster path, the unrecorded grids of the first are drained once, and from then on every launch waits and records.
+            if (!gd.users.empty() && !gd.multi) {
+                HT_HIP(c, hipDeviceSynchronize());
+                gd.multi = true;
+            }
+            gd.users.push_back(c);
+        }
+        if (gd.multi) {
+            if (!gd.last) HT_HIP(c, hipEventCreateWithFlags(&gd.last, hipEventDisableTiming));
+            else HT_HIP(c, hipStreamWaitEvent(c->stream, gd.last, 0));  // the previous cluster grid on this device (any context) has drained
+        }
+        hipLaunchKernelGGL(k_cs_meanshift_cluster, dim3(n * G), dim3(CL_NT), 0, c->stream, frames, frame_stride, c->W, c->H, lut, c->d_cs, first,
+                           calc_angles, c->dbg_cs_iters, G, c->d_cs_parts, c->d_cs_err, c->h_cs_err_direct, (long long)c->cs_barrier_budget, d_out,
+                           done_flags, done_seq);
         HT_HIP(c, hipGetLastError());
-        HT_HIP(c, hipEventRecord(ev, c->stream));
+        if (gd.multi) HT_HIP(c, hipEventRecord(gd.last, c->stream));
     } else {
         HtProfScope ps(c, "cs_meanshift");
-        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), (size_t)CS_REGION_CAP * 2, c->stream, frames, frame_stride, c->W, c->H, c->d_cs_hist, (int)nchunks,
+        hipLaunchKernelGGL(k_cs_meanshift, dim3(n), dim3(CS_NT), (size_t)CS_REGION_CAP * 2, c->stream, frames, frame_stride, c->W, c->H, hist, (int)nchunks,
                            c->d_cs, first, calc_angles, c->dbg_cs_iters, c->cs_region_cap, d_out);
         HT_HIP(c, hipGetLastError());
     }
+    c->cs_last_hist = hist;
     c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = (int)nchunks;
     return HT_OK;
 }
@@ -1039,9 +1098,16 @@ extern "C" ht_status ht_camshift_track_batch(ht_ctx *c, int32_t first, int32_t n
         if (c->cs_ring_count == ht_ctx::HT_CS_RING)
             return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_batch: too many enqueue-only calls outstanding (collect with ht_camshift_track_collect)");
         ht_ctx::HtCsSlot &sl = c->cs_ring[(c->cs_ring_head + c->cs_ring_count) % ht_ctx::HT_CS_RING];
-        ht_status st = launch_track(c, c->d_frames, c->frame_stride, first, n, calc_angles, sl.h_out);
+        bool flagged = false;
+        uint32_t seq = 0;
+        if (c->cs_flags && sl.h_flag) {
+            seq = ++c->cs_flag_seq ? c->cs_flag_seq : ++c->cs_flag_seq;  // never 0
+            for (int i = 0; i < n; i++) __atomic_store_n(&sl.h_flag[i], 0u, __ATOMIC_RELAXED);
+        }
+        ht_status st = launch_track(c, c->d_frames, c->frame_stride, first, n, calc_angles, sl.h_out, seq ? sl.h_flag : nullptr, seq, &flagged);
         if (st != HT_OK) return st;
-        HT_HIP(c, hipEventRecord(sl.ev, c->stream));
+        sl.seq = flagged ? seq : 0u;
+        if (!flagged) HT_HIP(c, hipEventRecord(sl.ev, c->stream));
         sl.n = n;
         c->cs_ring_count++;
         return HT_OK;
@@ -1064,7 +1130,28 @@ extern "C" ht_status ht_camshift_track_collect(ht_ctx *c, int32_t n, ht_cs_track
         return ht_fail(c, HT_ERR_STATE, "ht_camshift_track_collect: no enqueue-only ht_camshift_track_batch of n streams is pending");
     HT_HIP(c, hipSetDevice(c->device));
     ht_ctx::HtCsSlot &sl = c->cs_ring[c->cs_ring_head];
-    HT_HIP(c, hipEventSynchronize(sl.ev));  // the OLDEST outstanding call; later ones keep running
+    if (sl.seq) {  // the kernel marks every stream's slot word; poll them (the OLDEST outstanding call; later ones keep running)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < n; i++) {
+            uint64_t spins = 0;
+            while (__atomic_load_n(&sl.h_flag[i], __ATOMIC_ACQUIRE) != sl.seq) {
+                if ((++spins & 0xfff) == 0) {  // not there after a while: is the stream still running at all?
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                        const hipError_t q = hipStreamQuery(c->stream);
+                        if (q == hipSuccess) {
+                            if (__atomic_load_n(&sl.h_flag[i], __ATOMIC_ACQUIRE) == sl.seq) break;
+                            return ht_fail(c, HT_ERR_HIP, "ht_camshift_track_collect: the stream drained without the call's completion mark");
+                        }
+                        if (q != hipErrorNotReady) return ht_fail(c, HT_ERR_HIP, std::string("ht_camshift_track_collect: ") + hipGetErrorString(q));
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30))
+                            return ht_fail(c, HT_ERR_HIP, "ht_camshift_track_collect: timed out waiting for the call's completion mark");
+                    }
+                }
+            }
+        }
+    } else {
+        HT_HIP(c, hipEventSynchronize(sl.ev));  // the OLDEST outstanding call; later ones keep running
+    }
     std::memcpy(out, sl.h_out, sizeof(ht_cs_trackobj) * (size_t)n);
     c->cs_ring_head = (c->cs_ring_head + 1) % ht_ctx::HT_CS_RING;
     c->cs_ring_count--;
@@ -1114,6 +1201,7 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
             HT_HIP(c, hipGetLastError());
         }
         c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;
+        c->cs_last_hist = c->d_cs_hist;
     } else {
         for (int k = 0; k < ncalls; k++) {
             ht_cs_trackobj *d_out = c->d_cs_seq_out + (out_all ? (size_t)k * n : 0);
@@ -1167,10 +1255,10 @@ extern "C" ht_status ht_camshift_debug_hist(ht_ctx *c, int32_t stream, uint32_t 
     HT_HIP(c, hipStreamSynchronize(c->stream));
     if (model) HT_HIP(c, hipMemcpy(model, c->d_cs[stream].model, sizeof(uint32_t) * 4096, hipMemcpyDeviceToHost));
     if (current) {
-        if (stream < c->cs_last_first || stream >= c->cs_last_first + c->cs_last_n || c->cs_last_chunks <= 0)
+        if (stream < c->cs_last_first || stream >= c->cs_last_first + c->cs_last_n || c->cs_last_chunks <= 0 || !c->cs_last_hist)
             return ht_fail(c, HT_ERR_STATE, "ht_camshift_debug_hist: the stream was not part of the last track call");
         std::vector<uint32_t> part((size_t)c->cs_last_chunks * 4096);
-        HT_HIP(c, hipMemcpy(part.data(), c->d_cs_hist + (size_t)(stream - c->cs_last_first) * c->cs_last_chunks * 4096, part.size() * sizeof(uint32_t),
+        HT_HIP(c, hipMemcpy(part.data(), c->cs_last_hist + (size_t)(stream - c->cs_last_first) * c->cs_last_chunks * 4096, part.size() * sizeof(uint32_t),
                             hipMemcpyDeviceToHost));
         for (int b = 0; b < 4096; b++) {
             uint32_t v = 0;

@@ -292,6 +292,7 @@ static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) 
         else if (key == "force_exact") c->dbg_force_exact = iv;
         else if (key == "deep_bias") c->deep_bias = (uint32_t)std::max(0, iv);
         else if (key == "deep_v") c->dbg_deep_v = iv;
+        else if (key == "cs_flags") c->cs_flags = iv != 0;
         else if (key == "deep_grid") c->deep_grid = std::max(1, iv);
         else if (key == "split") c->opt_split = std::max(1, iv);
         else if (key == "cs_fused_min") c->cs_fused_min_streams = std::max(1, iv);
@@ -475,15 +476,16 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->h_cs_err_direct) (void)hipHostFree(c->h_cs_err_direct);
     for (auto &sl : c->cs_ring) {
         if (sl.h_out) (void)hipHostFree(sl.h_out);
+        if (sl.h_flag) (void)hipHostFree(sl.h_flag);
         if (sl.ev) (void)hipEventDestroy(sl.ev);
     }
+    ht_cluster_gate_forget(c);
     if (c->d_cs) (void)hipFree(c->d_cs);
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);
     if (c->d_cs_seq_out) (void)hipFree(c->d_cs_seq_out);
     if (c->d_cs_lut) (void)hipFree(c->d_cs_lut);
     if (c->d_cs_parts) (void)hipFree(c->d_cs_parts);
-    if (c->d_cs_ctr) (void)hipFree(c->d_cs_ctr);
     if (c->d_gather) (void)hipFree(c->d_gather);
     for (auto &a : release) {
         if (a.orphan) {  // whatever a context that has meanwhile re-bound elsewhere still had enqueued against it has to be through

@@ -349,7 +349,6 @@ struct ht_ctx {
     uint32_t *d_cs_hist = nullptr;  // per-stream current-frame histogram (4096 bins)
     ht_cs_trackobj *d_cs_out = nullptr;
     double *d_cs_lut = nullptr, *d_cs_parts = nullptr;  // cluster mean-shift: per-stream weight LUT, partial-sum exchange slots
-    unsigned long long *d_cs_ctr = nullptr;             // ... and arrival counters (zeroed before every launch)
     bool cs_cluster = true;                              // option cs_cluster=0 disables the cluster path
     uint32_t cs_cluster_min_px = 400000;                 // frames at least this large take it (option cs_cluster_min_px)
     ht_cs_trackobj *d_cs_seq_out = nullptr;  // ht_camshift_track_sequence: [calls][streams] results, one D2H at the end
@@ -364,7 +363,15 @@ struct ht_ctx {
         ht_cs_trackobj *h_out = nullptr;  // pinned, cs_ring_streams objects
         hipEvent_t ev = nullptr;
         int n = 0;
+        // completion without an event (option cs_flags, cluster path): the kernel stores `seq` into h_flag[stream] (pinned, system scope,
+        // after the stream's track object); the collect call polls the n words.  An event record is a barrier packet of its own on the
+        // stream — two of them per step (this one and the cluster gate's) were the 10 us between a step's last and the next step's
+        // first kernel (rocprofv3 kernel trace, LABLOG.md round 5).
+        uint32_t *h_flag = nullptr;
+        uint32_t seq = 0;  // 0: this slot's call is marked by the event
     };
+    uint32_t cs_flag_seq = 0;
+    bool cs_flags = true;
     HtCsSlot cs_ring[HT_CS_RING];
     int cs_ring_head = 0, cs_ring_count = 0, cs_ring_streams = 0;
     uint32_t *h_cs_err_direct = nullptr;  // pinned word the cluster kernel itself sets when a barrier times out (read with a ring slot: no copy)
@@ -380,6 +387,7 @@ struct ht_ctx {
     bool cs_attr_set = false;         // > 64 KB dynamic LDS enabled for the camshift kernels on this context's device
     int cs_region_cap = 40960;        // pixels of the LDS-cached search region (option cs_region=0 disables it)        // option cs_keep_hist: the fused kernel also writes its histogram for ht_camshift_debug_hist
     int cs_last_first = 0, cs_last_n = 0, cs_last_chunks = 0;  // layout of d_cs_hist after the last track call (debug read-back)
+    const uint32_t *cs_last_hist = nullptr;                    // ... and which half of d_cs_hist it used
 
     std::vector<std::pair<void *, size_t>> user_allocs;  // ht_device_alloc buffers still alive (pointer, bytes): freed by ht_destroy at the latest
 
@@ -420,6 +428,7 @@ struct HtProfScope {
 };
 
 // implemented in the .hip files ---------------------------------------------------------------------------
+void ht_cluster_gate_forget(const ht_ctx *ctx);             // ht_camshift.hip
 ht_status ht_launch_pyramid(ht_ctx *ctx, uint32_t flags);   // ht_pyramid.hip
 ht_status ht_launch_scan(ht_ctx *ctx, uint32_t flags);      // ht_scan.hip
 ht_status ht_launch_scan_early(ht_ctx *ctx, uint32_t flags); // ht_scan.hip: called by ht_launch_pyramid after generation early_gen

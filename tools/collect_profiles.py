@@ -23,7 +23,8 @@ timer = {"k_gray_linear": "gray", "k_gray_rows": "gray", "k_resample": "resample
 traffic = {"_note": "HBM bytes from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/gpu_pmc.sh): bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.  "
            "On gfx950 FETCH_SIZE tallies 128-B requests as 64 B (MI355X_MICROARCH.md, HBM section); calibrated on k_gray_linear, whose traffic is known exactly "
            "(reads W*H*4, writes W*H per frame): gray_check.  per_step: bytes per detect step and bench timer name = every launch's OWN counters summed over the "
-           "launches the timer covers (resample = the k_resample launches + the tail kernel); per_launch: mean per launch and kernel."}
+           "launches the timer covers (resample = the k_resample launches + the tail kernel); per_launch: mean per launch and kernel; "
+           "valu_per_step: SQ_INSTS_VALU wave instructions of all kernels of a step (valu_per_launch: mean per launch and kernel)."}
 ks5 = glob.glob(os.path.join(G, "prof_c5", "**", "*kernel_stats.csv"), recursive=True)  # C5 (8 x 1080p feeds): kernel stats only
 if ks5:
     shutil.copy(ks5[0], os.path.join(P, f"{tag}_c5_kernel_stats.csv"))
@@ -62,8 +63,11 @@ for wl in ("c2", "c4", "c3"):
             b = (2 * v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
             pl[k] = round(b)
             ps[timer[k]] += b * launches[k] / steps
+    # SQ_INSTS_VALU (wave instructions) of every kernel of a step: the numerator of bench.py's valu_issue_frac
+    valu = sum(v["SQ_INSTS_VALU"] * launches[k] / steps for k, v in per.items() if "SQ_INSTS_VALU" in v and steps)
     if ps:
-        traffic[wl] = {"per_step": {k: round(v) for k, v in ps.items()}, "per_launch": pl}
+        traffic[wl] = {"per_step": {k: round(v) for k, v in ps.items()}, "per_launch": pl, "valu_per_step": round(valu) if valu else None,
+                       "valu_per_launch": {k: round(v["SQ_INSTS_VALU"]) for k, v in per.items() if "SQ_INSTS_VALU" in v}}
 for name in ("tile_timeline_c2.txt", "tile_timeline_c4.txt", "rs_phases_c2.txt", "rs_phases_c4.txt"):  # shader-clock phase timelines (tools/gpu_tile_timeline.py, gpu_rs_phases.py)
     src = os.path.join(G, name)
     if os.path.exists(src):

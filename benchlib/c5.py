@@ -86,15 +86,16 @@ def stream_bench(env, a, feeds=1, steps=300, warm_cycles=1, cpu_seconds=0.0):
         """inputs resident in HBM.  A track step is enqueued before the previous step's results are waited for (two
         outstanding; the library keeps enqueue-only results in a ring of pinned slots): a feed's frame i + 1 does not
         depend on the HOST having seen the result of frame i — the search window lives on the device.  A detect step
-        drains the pipeline first: its best faces come back to the host, which floors them and calls initTracker."""
+        is enqueued behind them, the pipeline is drained, then its best faces come back to the host, which floors them and
+        calls initTracker (asynchronous: the next track step is enqueued right behind it)."""
         pend = []
         for i in range(k):
             ctx.bind_device(dev.data_ptr() + (i % NUNIQ) * sbytes, K)
             if is_detect(i):
+                enqueue(i)  # right behind the track steps in flight: the GPU does not idle while the host drains them
                 while pend:
                     j = pend.pop(0)
                     on_result(j, collect(j))
-                enqueue(i)
                 on_result(i, collect(i))
             else:
                 enqueue(i)

@@ -44,10 +44,11 @@ def _newer(target: str, deps) -> bool:
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, "ht_internal.h"), os.path.join(CSRC, "ht_cascade_gen.inc"), os.path.join(ROOT, "include", "headtrackr_hip.h"), os.path.abspath(__file__)]
+    deps = srcs + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
+    deps += [os.path.join(ROOT, "include", "headtrackr_hip.h"), os.path.abspath(__file__)]
     if force or _newer(LIB, deps):
         objs, procs = [], []
-        for s in srcs:  # the translation units are independent: compile them side by side (ht_scan.hip alone takes ~1.5 min)
+        for s in srcs:  # the translation units are independent: compile them side by side (the whole library: ~6 s)
             o = os.path.splitext(s)[0] + ".o"
             if force or _newer(o, deps):
                 cmd = [HIPCC, *HIP_FLAGS, *EXTRA_FLAGS.get(os.path.basename(s), []), "-c", s, "-o", o]

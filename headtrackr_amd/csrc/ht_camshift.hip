@@ -984,7 +984,25 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
     if (first < 0 || first + n > c->cs_streams) return ht_fail(c, HT_ERR_INVALID, "ht_camshift_init_batch: stream range not reserved");
     HT_HIP(c, hipSetDevice(c->device));
     ht_cs_rect *d_rects = reinterpret_cast<ht_cs_rect *>(c->d_cs_out);  // scratch: sizeof(ht_cs_trackobj) >= sizeof(ht_cs_rect); enqueue-only track calls keep their results in the pinned ring
-    HT_HIP(c, hipMemcpyAsync(d_rects, rects, sizeof(ht_cs_rect) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    // rects[] is the caller's (pageable) memory: staged in a pinned buffer of the context, so the copy is asynchronous and the call
+    // does not wait for the stream — a streaming host enqueues the next track step right behind initTracker (the stream synchronisation
+    // that used to end this call was 15-20 us of idle GPU per detect step of the C5 loop)
+    if (c->h_cs_rects_cap < n) {
+        if (c->h_cs_rects) {
+            HT_HIP(c, hipStreamSynchronize(c->stream));
+            (void)hipHostFree(c->h_cs_rects);
+        }
+        c->h_cs_rects = nullptr, c->h_cs_rects_cap = 0;
+        if (hipHostMalloc(reinterpret_cast<void **>(&c->h_cs_rects), sizeof(ht_cs_rect) * (size_t)c->cs_streams, hipHostMallocDefault) != hipSuccess)
+            return ht_fail(c, HT_ERR_NOMEM, "ht_camshift_init_batch: hipHostMalloc failed");
+        c->h_cs_rects_cap = c->cs_streams;
+        if (!c->ev_cs_rects) HT_HIP(c, hipEventCreateWithFlags(&c->ev_cs_rects, hipEventDisableTiming));
+    } else {
+        HT_HIP(c, hipEventSynchronize(c->ev_cs_rects));  // the previous call's copy has left the staging buffer (long ago, normally)
+    }
+    std::memcpy(c->h_cs_rects, rects, sizeof(ht_cs_rect) * (size_t)n);
+    HT_HIP(c, hipMemcpyAsync(d_rects, c->h_cs_rects, sizeof(ht_cs_rect) * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HT_HIP(c, hipEventRecord(c->ev_cs_rects, c->stream));
     {
         HtProfScope ps(c, "cs_init");
         // few streams with tall rects: rows spread over G workgroups per stream (one workgroup per stream would leave the chip idle)
@@ -999,7 +1017,6 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
         }
         HT_HIP(c, hipGetLastError());
     }
-    HT_HIP(c, hipStreamSynchronize(c->stream));  // rects[] is the caller's (pageable) memory
     return HT_OK;
 }
 

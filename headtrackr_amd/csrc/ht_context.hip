@@ -293,6 +293,7 @@ static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) 
         else if (key == "deep_bias") c->deep_bias = (uint32_t)std::max(0, iv);
         else if (key == "deep_v") c->dbg_deep_v = iv;
         else if (key == "cs_flags") c->cs_flags = iv != 0;
+        else if (key == "fp_sparse") c->fp_sparse = iv != 0;
         else if (key == "deep_grid") c->deep_grid = std::max(1, iv);
         else if (key == "split") c->opt_split = std::max(1, iv);
         else if (key == "cs_fused_min") c->cs_fused_min_streams = std::max(1, iv);
@@ -460,6 +461,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
     if (c->d_deep_feats) (void)hipFree(c->d_deep_feats);
     if (c->d_patch_feats) (void)hipFree(c->d_patch_feats);
     if (c->d_packed_feats) (void)hipFree(c->d_packed_feats);
+    if (c->d_fp_feats) (void)hipFree(c->d_fp_feats);
     if (c->d_stages) (void)hipFree(c->d_stages);
     if (c->d_frames_own) (void)hipFree(c->d_frames_own);
     if (c->d_frames_back) (void)hipFree(c->d_frames_back);
@@ -480,6 +482,8 @@ extern "C" void ht_destroy(ht_ctx *c) {
         if (sl.ev) (void)hipEventDestroy(sl.ev);
     }
     ht_cluster_gate_forget(c);
+    if (c->h_cs_rects) (void)hipHostFree(c->h_cs_rects);
+    if (c->ev_cs_rects) (void)hipEventDestroy(c->ev_cs_rects);
     if (c->d_cs) (void)hipFree(c->d_cs);
     if (c->d_cs_hist) (void)hipFree(c->d_cs_hist);
     if (c->d_cs_out) (void)hipFree(c->d_cs_out);

@@ -248,6 +248,10 @@ struct ht_ctx {
     HtDeepFeature *d_deep_feats = nullptr;
     HtPatchFeature *d_patch_feats = nullptr;
     HtPackedFeature *d_packed_feats = nullptr;  // features of stages >= split_stage (index 0 = first feature of that stage)
+    // every feature in the packed 32-byte form with TILE offsets (off[] relative to a window's LDS base, a1i = alpha[2k+1] * 1e8): the
+    // tile kernel's feature-parallel sparse phase reads one record per lane (nullptr: cascade not decimal / more than 5 points)
+    HtPackedFeature *d_fp_feats = nullptr;
+    bool fp_sparse = true;  // option fp_sparse=0: the sparse stages always run as four feature slices (A/B)
     uint32_t packed_count = 0, packed_first = 0; // number of packed features / global index of the first one (0 count = unusable)
     bool builtin_cascade = false;  // blob == the cascade ht_cascade_gen.inc was generated from
     uint32_t deep_bias = 1;        // tile kernel hands survivors to the deep kernel when n*bias*ceil(count/64) <= count
@@ -370,6 +374,9 @@ struct ht_ctx {
         uint32_t *h_flag = nullptr;
         uint32_t seq = 0;  // 0: this slot's call is marked by the event
     };
+    ht_cs_rect *h_cs_rects = nullptr;  // pinned staging of ht_camshift_init_batch's rects
+    int h_cs_rects_cap = 0;
+    hipEvent_t ev_cs_rects = nullptr;  // its copy to the device has been issued and completed
     uint32_t cs_flag_seq = 0;
     bool cs_flags = true;
     HtCsSlot cs_ring[HT_CS_RING];

@@ -156,7 +156,7 @@ __device__ __forceinline__ double eval_stage_lds(const uint8_t *lds, uint32_t B,
 template <bool GEN>
 __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *__restrict__ arena, uint64_t arena_stride,
                                                    const HtTileRec *__restrict__ tile_recs, const HtTileFeature *__restrict__ feats,
-                                                   const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,
+                                                   const HtPackedFeature *__restrict__ fp_feats, const HtDevStage *__restrict__ stages, int nstages, int split, uint32_t deep_bias,
                                                    int stop_stage, int force_exact, uint32_t tiles_per_frame, uint32_t total_tiles, HtQueueEntry *__restrict__ queue,
                                                    uint32_t queue_cap, ht_hit *__restrict__ hits, uint32_t hit_cap,
                                                    HtCounters *__restrict__ ctr, unsigned long long *__restrict__ stats) {
@@ -172,6 +172,12 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 #ifndef HT_TILE_WAVEQ
 #define HT_TILE_WAVEQ 1
 #endif
+#ifndef HT_TILE_FPAR
+#define HT_TILE_FPAR 1  // feature-parallel sparse phase (0: always the four feature slices)
+#endif
+#ifndef HT_TILE_FPCAP
+#define HT_TILE_FPCAP 4096  // upper bound of the pair count whatever the stage (A/B)
+#endif
 #ifndef HT_TILE_MERGE_FROM
 #define HT_TILE_MERGE_FROM 2  // the first stage after which the wavefronts compare their survivor counts
 #endif
@@ -180,7 +186,9 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
     // window ids (a wavefront enumerates at most MAXWIN / 4 = 512 windows), rows 32-37 = three buffers of 64 per-survivor integer
     // stage sums (36 dwords of tail per row: 32 used), row 38 = the wavefronts' survivor counts (two parities x 4).
     constexpr int WQ_ROWS = MAXWIN / NT, WQ_CAP = WQ_ROWS * 64;
-    static_assert(NT != 256 || GH >= 4 * WQ_ROWS + 7, "wave-private queues do not fit the row tails");
+    static_assert(NT != 256 || GH >= 4 * WQ_ROWS + 11, "wave-private queues do not fit the row tails");
+    // rows 39-42: per wavefront the LDS bases of the tile's surviving windows in rank order (feature-parallel sparse phase)
+#define FPB(w_, i_) (*reinterpret_cast<uint16_t *>(&lds[P12_BASE + 160 + (4 * WQ_ROWS + 7 + (w_)) * G_PITCH + (((uint32_t)(i_)&63u) << 1)]))
 #define QW(w_, e_) QB(0, (w_) * WQ_CAP + (e_))
 #define SF(b_, l_) (*reinterpret_cast<uint32_t *>(&lds[P12_BASE + 160 + (4 * WQ_ROWS + 2 * (b_) + ((l_) >> 5)) * G_PITCH + (((l_)&31u) << 2)]))
 #define SCNT(p_) (reinterpret_cast<uint32_t *>(&lds[P12_BASE + 160 + (4 * WQ_ROWS + 6) * G_PITCH + (p_) * 16]))
@@ -190,6 +198,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 #define QW(w_, e_) QB(0, 0)
 #define SF(b_, l_) (*SCNT(0))
 #define SCNT(p_) (&s_qbase)
+#define FPB(w_, i_) (*reinterpret_cast<uint16_t *>(&s_qbase))
     constexpr int WQ_CAP = 0;
 #endif
 
@@ -465,15 +474,48 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             const uint32_t wid = alive ? (uint32_t)QW(j, e) : 0u;
             const uint32_t yy = __umul24(wid, S.div_magic) >> 20, xx = wid - __umul24(yy, (uint32_t)S.tw2);
             const uint32_t Bw = 2u * (yy * PITCH0 + xx);
+            // Feature-parallel sparse phase.  Few windows left (most tiles from stage 4 on hold 1 - 16): one lane per (window, feature)
+            // pair instead of one lane per window — the stage's features spread over the workgroup's 256 lanes, each lane reading its
+            // feature's offsets from a packed 32-byte record and adding its alpha to the window's integer sum in LDS when the feature
+            // fires.  A lane = survivor pass costs a wavefront the stage's whole feature list whatever the survivor count (1 - 20 of
+            // 64 lanes busy); the pair form costs ~48 instructions per 256 pairs (HT_GEN_FP_MAXPAIRS[s] is where the two meet,
+            // tools/gen_cascade_code.py).  Same integer sums, same decisions.  Measured (round 5, LABLOG.md): -5.5 % VALU and -21 % LDS
+            // instructions per launch, the kernel -2 ... -4 %; evaluating SEVERAL stages' features in one phase for <= 16 windows (fewer
+            // latency chains, 3 - 4 x the pairs because most windows die in the first of them) was 8 - 12 % slower: removed.
             for (; s < wq_lim; s++) {
                 if (s == stop_stage) return;
-                const uint32_t n_alive = (uint32_t)__popcll(__ballot(alive));
+                const unsigned long long am = __ballot(alive);
+                const uint32_t n_alive = (uint32_t)__popcll(am);
                 if (tid == 0 && my_stats) atomicAdd(&my_stats[s], (unsigned long long)n_alive);
                 const uint32_t bi = (uint32_t)s % 3u;
-                const uint32_t part = ht_gen_stage_slice(s, (int)wv, lds + (alive ? Bw : 0u));
-                if (alive && part) atomicAdd(&SF(bi, lane), part);
+                const uint32_t nf = HT_GEN_NFEAT[s], npairs = n_alive * nf;
+                const bool fpar = HT_TILE_FPAR && fp_feats != nullptr && npairs <= min(HT_GEN_FP_MAXPAIRS[s], (uint32_t)HT_TILE_FPCAP);
+                uint32_t fslot = lane;  // the window's entry of the sum buffer: its lane, or its rank among the survivors
+                if (fpar) {
+                    fslot = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
+                    if (alive) FPB(wv, fslot) = (uint16_t)Bw;  // this wavefront's own copy: every wavefront holds every survivor
+                    const HtPackedFeature *frec = fp_feats + HT_GEN_FIRST[s];
+                    const uint32_t magic = HT_GEN_NFMAGIC[s];
+                    for (uint32_t p0 = wv * 64u; p0 < npairs; p0 += 256u) {
+                        const uint32_t p = p0 + lane;
+                        const bool on = p < npairs;
+                        const uint32_t pc = on ? p : 0u;
+                        const uint32_t si = __umul24(pc, magic) >> 20, k = pc - __umul24(si, nf);  // pc < 1024, magic < 2^18: the product needs 28 bits
+                        const uint4 r0 = reinterpret_cast<const uint4 *>(frec + k)[0];
+                        uint4 r1 = reinterpret_cast<const uint4 *>(frec + k)[1];
+                        asm volatile("" : "+v"(r1.x), "+v"(r1.z));  // both words with the first load: the alpha must not become a load of its own behind the decision
+                        const uint8_t *wb = lds + (uint32_t)FPB(wv, si);
+                        const uint32_t p0v = wb[r0.x & 0xffffu], p1v = wb[r0.x >> 16], p2v = wb[r0.y & 0xffffu], p3v = wb[r0.y >> 16], p4v = wb[r0.z & 0xffffu];
+                        const uint32_t n0v = wb[r0.z >> 16], n1v = wb[r0.w & 0xffffu], n2v = wb[r0.w >> 16], n3v = wb[r1.x & 0xffffu], n4v = wb[r1.x >> 16];
+                        const uint32_t pmin = min(min(min(p0v, p1v), min(p2v, p3v)), p4v), nmax = max(max(max(n0v, n1v), max(n2v, n3v)), n4v);
+                        if (on && pmin > nmax) atomicAdd(&SF(bi, si), r1.z);  // r1.z = a1i = alpha[2k+1] * 1e8
+                    }
+                } else {
+                    const uint32_t part = ht_gen_stage_slice(s, (int)wv, lds + (alive ? Bw : 0u));
+                    if (alive && part) atomicAdd(&SF(bi, lane), part);
+                }
                 __syncthreads();
-                const uint32_t Fv = SF(bi, lane);
+                const uint32_t Fv = SF(bi, fslot);
                 // the buffer of stage s-1 (= s+2 mod 3): every wavefront read it before this stage's barrier, stage s+2 adds to it after the next one
                 if (wv == 0) SF((uint32_t)(s + 2) % 3u, lane) = 0u;
                 bool pass = (Fv >= HT_GEN_FMIN[s]) & alive;
@@ -1208,6 +1250,30 @@ ht_status ht_scan_tile_tables(ht_ctx *c) {
     (void)tile_ok;
     HT_HIP(c, hipMalloc(&c->d_tile_feats, tf.size() * sizeof(HtTileFeature)));
     HT_HIP(c, hipMemcpy(c->d_tile_feats, tf.data(), tf.size() * sizeof(HtTileFeature), hipMemcpyHostToDevice));
+    {   // packed per-lane form of the same offsets for the tile kernel's feature-parallel sparse phase: slots past a polarity's point
+        // count repeat its first point (min / max are idempotent), alpha[2k+1] * 1e8 as the integer the generated stages add
+        std::vector<HtPackedFeature> fp(c->nfeat);
+        bool ok = c->decimal_alphas;
+        for (uint32_t k = 0; k < c->nfeat && ok; k++) {
+            const HtTileFeature &t = tf[k];
+            const HtBlobFeature &f = c->h_feats[k];
+            HtPackedFeature &q = fp[k];
+            std::memset(&q, 0, sizeof(q));
+            if (t.np == 0 || t.nn == 0 || t.np > 5 || t.nn > 5) ok = false;
+            for (uint32_t j = 0; j < 5 && ok; j++) {
+                const uint32_t jp = j < t.np ? j : 0u, jn = j < t.nn ? j : 0u;
+                q.off[j] = (uint16_t)((t.po[jp >> 1] >> (16 * (jp & 1))) & 0xffffu);
+                q.off[5 + j] = (uint16_t)((t.no[jn >> 1] >> (16 * (jn & 1))) & 0xffffu);
+            }
+            const double a0 = std::nearbyint(f.alpha[0] * 1e8), a1 = std::nearbyint(f.alpha[1] * 1e8);
+            if (!(a1 > 0 && a1 < 2147483648.0 && a0 == -a1)) ok = false;
+            q.a0i = (int32_t)a0, q.a1i = (int32_t)a1;
+        }
+        if (ok && c->nfeat) {
+            HT_HIP(c, hipMalloc(&c->d_fp_feats, fp.size() * sizeof(HtPackedFeature)));
+            HT_HIP(c, hipMemcpy(c->d_fp_feats, fp.data(), fp.size() * sizeof(HtPackedFeature), hipMemcpyHostToDevice));
+        }
+    }
 
     // patch-offset form for k_scan_deep
     std::vector<HtPatchFeature> pf(c->nfeat);
@@ -1372,11 +1438,11 @@ static ht_status launch_tiles(ht_ctx *c, uint32_t flags, hipStream_t stream, uin
     HtProfScope ps(c, "scan_tiles", stream);
     if (gen)
         hipLaunchKernelGGL(k_scan_tiles<true>, dim3((total + 7u) & ~7u), dim3(NT), 0, stream, c->d_arena, c->arena_stride,
-                           c->d_tile_recs + first, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
+                           c->d_tile_recs + first, c->d_tile_feats, c->fp_sparse ? c->d_fp_feats : nullptr, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
                            c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
     else
         hipLaunchKernelGGL(k_scan_tiles<false>, dim3((total + 7u) & ~7u), dim3(NT), 0, stream, c->d_arena, c->arena_stride,
-                           c->d_tile_recs + first, c->d_tile_feats, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
+                           c->d_tile_recs + first, c->d_tile_feats, c->fp_sparse ? c->d_fp_feats : nullptr, c->d_stages, (int)c->nstages, split, c->deep_bias, stop_stage, force_exact, count, total,
                            c->d_queue, c->queue_capacity, c->d_hits, c->hit_capacity, c->d_counters, stats);
     HT_HIP(c, hipGetLastError());
     return HT_OK;

@@ -346,7 +346,7 @@ headtrackr.ccv.detect_objects_batch = function (frames, n, w, h, cascade, interv
  *                                           last batch, hits, batches}; neighbors 0 / confidence -10000 = no face (facetrackr.js:239)
  *     detect(min_neighbors, set)           -> Array<Array<rect>>: exactly ccv.detect_objects' result per frame (parity path)
  *     whitebalance(set)                    -> Float64Array(n): getWhitebalance per frame, fused into a detect batch's gray pass
- *     detectStep(set) / trackStep(set) / trackEnqueue(set) + trackCollect() / ingest(pinned) / swap()   K frame-synchronous live feeds, one time step per call (below)
+ *     detectStep(set) (= detectStepEnqueue + detectStepFinish) / trackStep(set) / trackEnqueue(set) + trackCollect() / ingest(pinned) / swap()   K frame-synchronous live feeds, one time step per call (below)
  *     initTrackers(rects, set) / trackSequence(sets[], calcAngles, outAll) -> Float64Array(9 n [* calls]): n camshift streams,
  *                                           one track() per listed frame set, ONE host call (ht_camshift_track_sequence)
  *     destroy() */
@@ -422,9 +422,18 @@ headtrackr.ccv.DeviceBatch = function (w, h, n, opts) {
   const bind0 = function (set) { if (set >= 0) A.bindDevice(ctxs[0], dev, set * setBytes, n, fbytes); bound = -1; };
   this.ingest = function (pinned) { A.uploadAsync(ctxs[0], pinned, n); };
   this.swap = function () { A.swapFrames(ctxs[0]); bound = -1; };
-  this.detectStep = function (set, min_neighbors) {
+  /*   detectStepEnqueue(set) / detectStepFinish(min_neighbors)   the two halves of detectStep: a streaming host enqueues the detect of
+   *                                  step i right behind the track steps still in flight, collects THOSE (trackCollect), and only then
+   *                                  waits for the best faces — the GPU does not idle while the host drains its pipeline */
+  this.detectStepEnqueue = function (set) {
     bind0(set === undefined ? 0 : set);
     A.detectEnqueue(ctxs[0], A.INPUT_RGBA);
+  };
+  this.detectStep = function (set, min_neighbors) {
+    this.detectStepEnqueue(set);
+    return this.detectStepFinish(min_neighbors);
+  };
+  this.detectStepFinish = function (min_neighbors) {
     const r = A.collectBest(ctxs[0], min_neighbors === undefined ? 1 : min_neighbors, -1);
     const rects = new Int32Array(4 * n);
     for (let f = 0; f < n; f++) {

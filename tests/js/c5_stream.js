@@ -32,12 +32,12 @@ fs.closeSync(fd);
 const isDetect = function (i) { return i % 30 === 0; };
 const step = function (i, set) { return isDetect(i) ? b.detectStep(set) : b.trackStep(set, true); };
 /* the same steps with TWO track steps outstanding (bench.py's resident loop): a track step is enqueued before the previous one is collected;
- * a detect step drains the pipeline first (its best faces come back to JS, which floors them and calls initTracker).  onResult(i, r) in step order. */
+ * a detect step is enqueued right behind them, then the pipeline is drained, then its best faces come back to JS (which floors them and calls initTracker).  onResult(i, r) in step order. */
 const pipelined = function (from, to, setOf, onResult) {
   const pend = [];
   const drain1 = function () { const j = pend.shift(); onResult(j, b.trackCollect()); };
   for (let i = from; i < to; i++) {
-    if (isDetect(i)) { while (pend.length) drain1(); onResult(i, b.detectStep(setOf(i))); }
+    if (isDetect(i)) { b.detectStepEnqueue(setOf(i)); while (pend.length) drain1(); onResult(i, b.detectStepFinish()); }
     else { b.trackEnqueue(setOf(i), true); pend.push(i); if (pend.length > 1) drain1(); }
   }
   while (pend.length) drain1();

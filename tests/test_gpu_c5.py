@@ -90,6 +90,67 @@ def test_c5_shape_feeds_in_one_context_vs_oracle(cascade, feeds):
         dev.free()
 
 
+@pytest.mark.parametrize("feeds", [8, 1])
+def test_c5_pipelined_loop_as_the_bench_issues_it(cascade, feeds):
+    """bench.py's TIMED C5 loop (round 5): two track steps outstanding; a detect step is enqueued right behind them BEFORE their
+    results are collected, its best faces are collected after, initTracker no longer waits for the stream (rects staged in pinned
+    memory) and the next track step is enqueued right behind it; completion of an enqueue-only track call is a mark the kernel writes
+    into the pinned slot (no event).  91 steps = three detect steps; every best face and every track object == the oracle's."""
+    K, steps = feeds, 91
+    uniq = synth.stream_feed_frames(NUNIQ, W, H, 0)
+    c = Context()
+    dev = c5_device_steps(uniq, K)
+    sbytes = K * W * H * 4
+    try:
+        c.set_geometry(W, H, K)
+        c.camshift_reserve(K)
+        results = {}
+        pend = []
+
+        def collect(i):
+            if i % 30 == 0:
+                best = c.detect_collect_best(1)[0].copy()
+                c.camshift_init(floored_rects(best, W, H))
+                results[i] = best
+            else:
+                results[i] = c.camshift_track_collect(K).copy()
+
+        for i in range(steps):
+            c.bind_device(dev.ptr + (i % NUNIQ) * sbytes, K)
+            if i % 30 == 0:
+                c.detect_enqueue(0)
+                while pend:
+                    collect(pend.pop(0))
+                collect(i)
+            else:
+                c.camshift_track(K, calc_angles=True, fetch=False)
+                pend.append(i)
+                if len(pend) > 1:
+                    collect(pend.pop(0))
+        while pend:
+            collect(pend.pop(0))
+        oracles = [None] * K
+        stats = []
+        for i in range(steps):
+            got = results[i]
+            for f in range(K):
+                fr = uniq[synth.stream_frame_index(i, f, NUNIQ)]
+                if i % 30 == 0:
+                    want = ho.best_faces(fr[None], cascade.blob, 1)[0]
+                    for k in ("x", "y", "width", "height", "confidence", "neighbors"):
+                        assert got[k][f] == want[k], (i, f, k)
+                    oracles[f] = ho.Camshift(True)
+                    oracles[f].init_tracker(fr, floored_rects(got, W, H)[f])
+                else:
+                    sw, to = oracles[f].track(fr)
+                    cs_check(got[f], sw, to, stats, where=("c5-pipelined", K, f, i))
+        assert len(stats) == K * (steps - 4)
+        cs_all_exact(stats, f"C5 pipelined loop, {K} feed(s), {steps} steps")
+    finally:
+        c.close()
+        dev.free()
+
+
 def test_enqueue_only_track_calls_pipeline_through_the_result_ring(cascade):
     """bench.py's timed C5 loop keeps TWO track steps outstanding (step i + 1 is enqueued before step i is collected); the library allows
     four (results in a ring of pinned slots the kernels write directly).  Here: 4 feeds x 1080p, detect + initTracker, then the 29 track

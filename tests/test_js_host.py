@@ -49,8 +49,6 @@ def test_js_host_parity_on_gpu(tmp_path):
     dbg = load_golden("debug.json")
     job = {"detect": [], "camshift": [], "facetrackr": [], "pipeline": [], "mainjs": []}
     for c in det["cases"]:
-        if c["w"] > 640:
-            continue
         job["detect"].append(dict(name=c["name"], w=c["w"], h=c["h"], interval=3 if "interval3" in c["name"] else 5,
                                   frame=ffile(c["gen"], c["w"], c["h"]), golden={k: c[k] for k in ("whitebalance", "gray_rgba_crc", "raw", "grouped", "min_neighbors")}))
     for c in cam["cases"]:

@@ -171,6 +171,11 @@ def lane_model(frames, c, scheme="strip4"):
             f = c.features[int(st["first"]) + k]
             n += sum(1 for t in range(int(f["size"])) if f["pz"][t] >= 0) + sum(1 for t in range(int(f["size"])) if f["nz"][t] >= 0)
         pts.append(n)
+    nfeat = [int(c.stages[j]["count"]) for j in range(NST)]
+    FP_PASS = 16  # sample-units of one feature-parallel pass: 64 (window, feature) lanes x (10 padded points + the per-lane record)
+    fpar = np.zeros(NST)   # as it runs, but a tile with few survivors evaluates (window, feature) pairs across the lanes when that is cheaper
+    both = np.zeros(NST)   # ... and the queues packed into full wavefronts for 64 < T <= 256
+    hist_T = np.zeros((NST, 8), dtype=np.int64)  # tiles by survivor count at stage entry: 1-4, 5-8, 9-16, 17-32, 33-64, 65-128, 129-256, > 256
     now = np.zeros(NST)
     bal = np.zeros(NST)
     two = np.zeros(NST)
@@ -210,10 +215,18 @@ def lane_model(frames, c, scheme="strip4"):
                                 passes = 1 if T <= 64 else int(sum(-(-int(x) // 64) for x in cnt[:, j]))
                                 now[j] += pts[j] * passes
                                 bal[j] += pts[j] * (1 if T <= 64 else (-(-T // 64) if T <= 256 else passes))
+                                fp = -(-T * nfeat[j] // 64) * FP_PASS
+                                fpar[j] += min(pts[j] * passes, fp) if T <= 64 else pts[j] * passes
+                                both[j] += min(pts[j], fp) if T <= 64 else pts[j] * (-(-T // 64) if T <= 256 else passes)
+                                hist_T[j, min(7, max(0, int(np.ceil(np.log2(max(T, 1) / 4.0 + 1e-9))) if T > 4 else 0))] += 1
                             else:
                                 acc[j] += pts[j] * (1 if T <= 64 else int(sum(-(-int(x) // 64) for x in cnt[:, j])))
     print("stage:                ", " ".join(f"{j:8d}" for j in range(1, NST)))
-    for name, v in (("as it runs", now), ("balanced 64<T<=256", bal), ("two wavefronts/tile", two), ("full lanes", ideal)):
+    print("tiles by survivors at stage entry (1-4, 5-8, 9-16, 17-32, 33-64, 65-128, 129-256, > 256):")
+    for j in range(1, NST):
+        print(f"  stage {j}:", " ".join(f"{int(x):6d}" for x in hist_T[j]))
+    for name, v in (("as it runs", now), ("balanced 64<T<=256", bal), ("two wavefronts/tile", two), ("feature-parallel sparse", fpar), ("packed + feature-par.", both),
+                    ("full lanes", ideal)):
         print(f"{name:22s}", " ".join(f"{x / 1e3:8.0f}" for x in v[1:]), f"  total {v.sum() / 1e3:.0f} k sample-passes ({100 * v.sum() / now.sum():.0f} %)")
 
 

@@ -44,16 +44,25 @@ namespace {
 #endif
 
 constexpr int CS_NT = 512;          // threads of the mean-shift workgroup
-constexpr int HIST_NT = 256;
-// Partial histograms per stream: enough chunks to put ~1024 workgroups on the chip (a single 1080p stream gets 127, a
-// batch of >= 128 streams 8 each), each chunk >= 16384 pixels and a multiple of 4 * HIST_NT.
+#ifndef HT_HIST_NT
+#define HT_HIST_NT 1024
+#endif
+constexpr int HIST_NT = HT_HIST_NT;
+// Partial histograms per stream: enough chunks to put ~256 workgroups of 1024 threads on the chip (a single 1080p stream gets 127,
+// eight of them 32 each, a batch of >= 32 streams 8 each), each chunk >= 16384 pixels and a multiple of 4 * HIST_NT.  Round 5, same box,
+// the C5 track step of 8 / 1 feeds (tools/gpu_cs_step.py): 256 threads x ~1024 workgroups 39.1 / 27.8 us, 512 x 512: 36.5 / 24.6,
+// 1024 x 512: 36.4 / 24.2, 1024 x 256: 35.8 / 24.0 (a quarter of the chunk histograms to write and to sum), 8 loads in flight per
+// thread instead of 4: 39.4 / 26.8.
 #ifndef HT_HIST_MAXCHUNKS
 #define HT_HIST_MAXCHUNKS 128
 #endif
 #ifndef HT_HIST_UNROLL
 #define HT_HIST_UNROLL 4
 #endif
-inline uint32_t hist_max_chunks(int nstreams) { return (uint32_t)std::min(HT_HIST_MAXCHUNKS, std::max(8, (HT_HIST_MAXCHUNKS * 8) / std::max(nstreams, 1))); }
+#ifndef HT_HIST_TARGET_WGS
+#define HT_HIST_TARGET_WGS 256  // workgroups of a k_cs_hist launch, all streams together
+#endif
+inline uint32_t hist_max_chunks(int nstreams) { return (uint32_t)std::min(HT_HIST_MAXCHUNKS, std::max(8, HT_HIST_TARGET_WGS / std::max(nstreams, 1))); }
 inline void hist_chunks(uint32_t npix, uint32_t max_chunks, uint32_t *chunk_px, uint32_t *nchunks) {
     uint32_t n = std::min<uint32_t>((npix + 16383u) / 16384u, max_chunks);
     n = std::max<uint32_t>(n, 1u);

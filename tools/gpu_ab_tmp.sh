@@ -1,8 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
-for v in product fp0 fpc256 fpc512; do
+for v in product h512 h1024 h1024b h256u8; do
   L=""; [ $v != product ] && L=$GRAFT_REPO_ROOT/alt/$v.so
-  echo "== $v"
-  HEADTRACKR_HIP_LIB=$L timeout 200 python tools/gpu_kernel_times.py c2 "" 3 2>/dev/null | tail -1 | cut -c1-250
-  HEADTRACKR_HIP_LIB=$L timeout 200 python tools/gpu_kernel_times.py c4 "" 2 2>/dev/null | tail -1 | cut -c1-250
-done; done
+  for f in 8 1; do HEADTRACKR_HIP_LIB=$L timeout 200 python tools/gpu_cs_step.py $f 2>/dev/null | tail -1; done
+done

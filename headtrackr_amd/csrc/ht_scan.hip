@@ -175,9 +175,6 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
 #ifndef HT_TILE_FPAR
 #define HT_TILE_FPAR 1  // feature-parallel sparse phase (0: always the four feature slices)
 #endif
-#ifndef HT_TILE_FPCAP
-#define HT_TILE_FPCAP 4096  // upper bound of the pair count whatever the stage (A/B)
-#endif
 #ifndef HT_TILE_MERGE_FROM
 #define HT_TILE_MERGE_FROM 2  // the first stage after which the wavefronts compare their survivor counts
 #endif
@@ -489,7 +486,7 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
                 if (tid == 0 && my_stats) atomicAdd(&my_stats[s], (unsigned long long)n_alive);
                 const uint32_t bi = (uint32_t)s % 3u;
                 const uint32_t nf = HT_GEN_NFEAT[s], npairs = n_alive * nf;
-                const bool fpar = HT_TILE_FPAR && fp_feats != nullptr && npairs <= min(HT_GEN_FP_MAXPAIRS[s], (uint32_t)HT_TILE_FPCAP);
+                const bool fpar = HT_TILE_FPAR && fp_feats != nullptr && npairs <= HT_GEN_FP_MAXPAIRS[s];
                 uint32_t fslot = lane;  // the window's entry of the sum buffer: its lane, or its rank among the survivors
                 if (fpar) {
                     fslot = __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));

@@ -66,9 +66,11 @@ typedef struct ht_config {
                              *   cs_fused_min=N       streams per call from which camshift runs as one launch (default 192)
                              *   cs_seq_fused=0|1     track sequences inside one launch (1)       cs_keep_hist=1   keep histograms for ht_camshift_debug_hist
                              *   cs_cluster=0|1, cs_cluster_min_px=N, cs_region=N                 cluster / LDS-region paths of the few-stream schedule
-                             *   cs_barrier_budget=N  shader-clock cycles a cluster barrier may wait before the call fails with HT_ERR_STATE
+                             *   cs_barrier_budget=N  shader-clock cycles a cluster exchange may wait before the call fails with HT_ERR_STATE
+                             *   cs_flags=0|1         enqueue-only track calls of the cluster path are completed by marks in the pinned slot (1) or an event
+                             *   fp_sparse=0|1        tile kernel: sparse stages one lane per (window, feature) pair when <= 256 pairs are left (1)
                              *   graph_max_frames=N   batches up to N frames replay a captured hipGraph (256; 0 = never)
-                             *   split=S, deep_bias=B, deep_v=2|4, deep_grid=N                    tile kernel -> deep kernel hand-off
+                             *   split=S, deep_bias=B, deep_v=2|4, deep_grid=N                    tile kernel -> deep kernel hand-off (grid kept >= 16 wavefronts)
                              *   force_exact=1        every integer stage decision re-run on the sequential binary64 path
                              *   early_scan=1, rs_rpt, rs_minwg, rs_k, rs_group, rs_tailtable, rs_tailcap, rs_notail, rs_nofast, rs_nosort, rs_gennames
                              *   host_threads=N       worker threads of the host post-processing (0 = single-threaded)

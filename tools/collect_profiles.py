@@ -76,7 +76,11 @@ for name in ("tile_timeline_c2.txt", "tile_timeline_c4.txt", "rs_phases_c2.txt",
             print(f"REFUSED {name}: not a timeline (traceback / error / empty)")
             continue
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
-for name in ("default", "driver", "c5"):
+for name in ("cs_step.txt", "kernel_times.txt", "host_post.txt"):
+    src = os.path.join(G, name)
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
+for name in ("default", "driver", "driver_sub", "c5"):
     bj = os.path.join(G, f"bench_{name}.json")
     if os.path.exists(bj):
         shutil.copy(bj, os.path.join(P, f"{tag}_bench_{name}.json"))

@@ -14,11 +14,14 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 
 fi
 t0=$(date +%s)
 # the command the driver runs at round end (BENCH_rNN.json: 20 timed steps = a 5 ms block for the primary workload)
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "bench driver-style exit $? ($(( $(date +%s) - t0 )) s)"; cut -c1-300 $OUT/bench_driver.json
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver.json 2> $OUT/bench_driver.err; echo "bench driver-style exit $? ($(( $(date +%s) - t0 )) s, $(wc -c < $OUT/bench_driver.json) bytes)"; cut -c1-300 $OUT/bench_driver.json
+cp $OUT/bench_sub.json $OUT/bench_driver_sub.json 2>/dev/null  # the full record tree of the same run
 timeout 900 python bench.py --no-sub --cpu-seconds 0 > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "bench flag-less (c2 only) exit $?"; cut -c1-200 $OUT/bench_default.json
 timeout 120 python tools/gpu_host_post.py > $OUT/host_post.txt 2> $OUT/host_post.err; tail -3 $OUT/host_post.txt
 for o in "" host_threads=0; do timeout 120 python tools/gpu_kernel_times.py c2 $o 2>/dev/null | tail -1 >> $OUT/kernel_times.txt; done
 timeout 120 python tools/gpu_kernel_times.py c4 2>/dev/null | tail -1 >> $OUT/kernel_times.txt; cat $OUT/kernel_times.txt
+for f in 8 1; do timeout 200 python tools/gpu_cs_step.py $f 2>/dev/null | tail -1 >> $OUT/cs_step.txt; done; cat $OUT/cs_step.txt
+timeout 300 bash tools/gpu_c5_trace.sh cs_flags=1 > $OUT/c5_trace.txt 2>&1; tail -3 $OUT/c5_trace.txt
 if [ "${RUN_PROF:-1}" = 1 ]; then
 cd /tmp
 for wl in c2 c4 c3 c5; do

@@ -77,7 +77,18 @@ def enum_pairs(scheme, tw2, th, tw):
     return row, p, 2 * p < tw, 2 * p + 1 < tw
 
 
-def simulate(frames, c, scheme):
+def wave_pair_ranges(npairs, wv, nw, assign):
+    """[lo, hi) ranges of walking-order pair indices wavefront wv evaluates in stage 0: "block" = a contiguous 1/nw of the 32-pair batches
+    (the kernel as it is), "interleave" = every nw-th pass of 64 pairs"""
+    nbat = -(-npairs // 32)
+    if assign == "block":
+        per = -(-nbat // nw)
+        lo, hi = min(wv * per * 32, npairs), min((wv * per + per) * 32, npairs)
+        return [(b, min(b + 64, hi)) for b in range(lo, hi, 64)]
+    return [(b, min(b + 64, npairs)) for b in range(64 * wv, npairs, 64 * nw)]
+
+
+def simulate(frames, c, scheme, assign="block"):
     offs = [np.array(s1.stage_offsets(c, j, PITCH0, P12)) for j in range(NST)]
     cls = [np.bincount(o & 3, minlength=4) for o in offs]  # byte-read constants per (offset mod 4)
     act = np.zeros(NST)
@@ -98,14 +109,10 @@ def simulate(frames, c, scheme):
                     row, p, v0, v1 = enum_pairs(scheme, tw2, th, tw)
                     npairs = len(row)
                     # waves: contiguous quarters of the 32-pair batches (64 ids), a pass = 64 pairs
-                    nbat = -(-npairs // 32)
-                    per = -(-nbat // 4)
                     queues = []
                     for wv in range(4):
-                        lo, hi = min(wv * per * 32, npairs), min((wv * per + per) * 32, npairs)
                         q_ids = []
-                        for b in range(lo, hi, 64):
-                            e = min(b + 64, hi)
+                        for b, e in wave_pair_ranges(npairs, wv, 4, assign):
                             r_, p_, a0, a1 = row[b:e], p[b:e], v0[b:e], v1[b:e]
                             n = e - b
                             pad = 64 - n
@@ -144,21 +151,23 @@ def simulate(frames, c, scheme):
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "lanes":
         nframes = int(sys.argv[2]) if len(sys.argv) > 2 else 6
-        lane_model(synth.mixed_batch(nframes, 320, 240, seed0=1234), load_cascade())
+        for assign in ("block", "interleave"):
+            print(f"--- stage-0 passes dealt out: {assign}")
+            lane_model(synth.mixed_batch(nframes, 320, 240, seed0=1234), load_cascade(), assign=assign)
         return
     nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 6
     w, h = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (320, 240)
     c = load_cascade()
     frames = synth.mixed_batch(nframes, w, h, seed0=1234)
-    for scheme in ("rowmajor", "strip4", "strip12"):
-        act, issued = simulate(frames, c, scheme)
-        print(f"{scheme:9s}: LDS cycles {act.sum():.3e} for {issued.sum():.3e} conflict-free -> conflict share {100 * (1 - issued.sum() / act.sum()):.1f} % of all cycles")
+    for scheme, assign in (("rowmajor", "block"), ("strip4", "block"), ("strip4", "interleave"), ("strip12", "block")):
+        act, issued = simulate(frames, c, scheme, assign)
+        print(f"{scheme:9s} {assign:10s}: LDS cycles {act.sum():.3e} for {issued.sum():.3e} conflict-free -> conflict share {100 * (1 - issued.sum() / act.sum()):.1f} % of all cycles")
         print("    per stage cycles / conflict-free:", " ".join(f"{a / max(b, 1):.2f}" for a, b in zip(act, issued)), "| share of cycles:", " ".join(f"{100 * a / act.sum():.0f}%" for a in act))
 
 
 
 
-def lane_model(frames, c, scheme="strip4"):
+def lane_model(frames, c, scheme="strip4", assign="block"):
     """Wave passes of the stages after stage 0 as the kernel runs them (every wavefront walks its own queue in chunks of 64; once <= 64
     windows are left in the tile all four wavefronts take a quarter of the stage's features for all of them = one pass in all) against
     two alternatives: the queues balanced over the wavefronts whenever 64 < survivors <= 256, and two wavefronts per tile.
@@ -197,12 +206,11 @@ def lane_model(frames, c, scheme="strip4"):
                     npairs = len(row)
                     nbat = -(-npairs // 32)
                     for nw, acc in ((4, None), (2, two)):
-                        per = -(-nbat // nw)
                         cnt = np.zeros((nw, NST + 1), dtype=np.int64)  # windows of wavefront w alive at the entry of stage j
                         for wv in range(nw):
-                            lo, hi = min(wv * per * 32, npairs), min((wv * per + per) * 32, npairs)
-                            r_, p_ = row[lo:hi], p[lo:hi]
-                            for a, dx in ((v0[lo:hi], 0), (v1[lo:hi], 1)):
+                            sel = np.concatenate([np.arange(b, e) for b, e in wave_pair_ranges(npairs, wv, nw, assign)] + [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+                            r_, p_ = row[sel], p[sel]
+                            for a, dx in ((v0[sel], 0), (v1[sel], 1)):
                                 dd = d[np.minimum(r_, th - 1), np.minimum(2 * p_ + dx, tw - 1)][a]
                                 for j in range(1, NST):
                                     cnt[wv, j] += int((dd >= j).sum())

@@ -279,7 +279,7 @@ static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) 
         }
         const int iv = (int)std::max<long long>(std::min<long long>(v, 1ll << 30), -(1ll << 30));
         if (key == "rs_rpt") { if (iv >= 1 && iv <= HT_RS_MAX_PASSES) c->rs_rpt = iv; }
-        else if (key == "rs_tailtable") c->tail_table = iv != 0, c->tail_table_forced = true;
+        else if (key == "rs_tailtable") c->tail_table = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv), c->tail_table_forced = true;
         else if (key == "rs_tailcap") c->rs_tailcap = (uint64_t)std::max<long long>(v, 0);
         else if (key == "rs_notail") c->rs_notail = iv != 0;
         else if (key == "rs_nofast") c->rs_nofast = iv != 0;
@@ -676,7 +676,7 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
     // 128 x 720p but costs 3 % at 256 x 320x240, where its grid puts a 1024-thread workgroup on EVERY CU and its footprint keeps
     // the other batches' kernels from sharing them; the round-1 binary64 tail (41 VGPRs) is kept for batches that cover the chip.
     // Larger caps (generation 3 of C2 = 54 k pixels in the tail) lose with either kernel.
-    if (!c->tail_table_forced) c->tail_table = max_batch <= 128;
+    if (!c->tail_table_forced) c->tail_table = max_batch <= 128 ? 1 : 0;
     c->tail_first_gen = 0;
     if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
     if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;

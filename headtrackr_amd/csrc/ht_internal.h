@@ -284,7 +284,7 @@ struct ht_ctx {
     HtTailTapRef *d_tail_tapref = nullptr;   // per tail job: where its taps start
     HtTailGens h_tail;                       // per generation: job range and group count (kernel argument)
     bool deep_attr_set = false;              // k_scan_deep_lds: > 64 KB dynamic LDS enabled on this context's device
-    bool tail_table = true;  // k_resample_tail with host tap tables (false: the round-1 binary64 tail; option rs_tailtable)
+    int tail_table = 1;  // k_resample_tail with host tap tables: 1 = compact taps in LDS, 2 = taps from L2 / small footprint; 0: the round-1 binary64 tail (option rs_tailtable)
     bool tail_table_forced = false;  // option rs_tailtable given: ht_set_geometry keeps it instead of choosing by batch size
     bool rs_nofast = false, rs_nosort = false, rs_notail = false, rs_gennames = false;  // options of the same names (A/B, cross-checks)
     uint64_t rs_tailcap = 32768;     // destination pixels per frame the tail kernel takes at most (option rs_tailcap)

@@ -641,17 +641,24 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
 #define HT_TAIL_U 1  // groups per thread in flight: 1 = 68 VGPRs; 2-6 (96-240 VGPRs) measured no faster
 #endif
 constexpr int TAIL_NT = HT_TAIL_NT;
+#ifndef HT_TAIL_SMALL_WPS
+#define HT_TAIL_SMALL_WPS 8  // waves per SIMD the small-footprint tail leaves room for (8: <= 64 VGPRs)
+#endif
 // Taps come from tables the host built once per geometry (compact {a, (float)t} for the binary32 estimate, full binary64 form for the
 // fallback) and the pixels take the same binary32-estimate / integer-box-mean / binary64-fallback route as k_resample: the tail
 // used to spend ~135 binary64 instructions per group of 4 pixels on re-deriving taps and on the lerps.
-__global__ __launch_bounds__(TAIL_NT) void k_resample_tail(const HtResampleJob *__restrict__ jobs, const uint32_t *__restrict__ prefix,
+// LDS_TAPS = false (round 5, option rs_tailtable=2): the compact taps stay in global memory (a few KB per geometry, L1 / L2 resident) and
+// the register allocator leaves room for WPS waves per SIMD — the small-footprint form for batches that cover the chip, where the
+// 35 KB / 68-VGPR form keeps the other batches' kernels off every CU (see the tail plan in ht_context.hip).
+template <bool LDS_TAPS, int WPS>
+__global__ __launch_bounds__(TAIL_NT, WPS) void k_resample_tail(const HtResampleJob *__restrict__ jobs, const uint32_t *__restrict__ prefix,
                                                           const HtTailTapRef *__restrict__ tapref, const HtTapFast *__restrict__ tfast,
                                                           const HtTap *__restrict__ tfull, const HtTailGens G, uint8_t *__restrict__ arena,
                                                           uint64_t arena_stride, uint32_t nframes) {
     __shared__ HtResampleJob s_jobs[HT_TAIL_MAX_JOBS];
     __shared__ HtTailTapRef s_ref[HT_TAIL_MAX_JOBS];
     __shared__ uint32_t s_pref[HT_TAIL_MAX_JOBS + 1];
-    __shared__ HtTapFast s_taps[HT_TAIL_LDS_TAPS];  // the generation's compact taps: one global round trip less per group
+    __shared__ HtTapFast s_taps[LDS_TAPS ? HT_TAIL_LDS_TAPS : 1];  // the generation's compact taps: one global round trip less per group
     uint32_t fidx, item;
     if (!xcd_item(1u, nframes, &fidx, &item)) return;  // same frame -> XCD placement as the generations before
     uint8_t *frame = arena + (uint64_t)fidx * arena_stride;
@@ -667,7 +674,7 @@ __global__ __launch_bounds__(TAIL_NT) void k_resample_tail(const HtResampleJob *
             if (tid == 0) s_pref[nj] = total;
         }
         const uint32_t tap0 = G.tap_begin[g], ntap = G.tap_begin[g + 1] - tap0;
-        const bool taps_in_lds = ntap <= (uint32_t)HT_TAIL_LDS_TAPS;  // uniform
+        const bool taps_in_lds = LDS_TAPS && ntap <= (uint32_t)HT_TAIL_LDS_TAPS;  // uniform
         if (taps_in_lds)
             for (uint32_t i = (uint32_t)tid; i < ntap; i += TAIL_NT) s_taps[i] = tfast[tap0 + i];
         __syncthreads();
@@ -914,8 +921,11 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
     }
     if (c->tail_first_gen > 0 && c->tail_first_gen <= dbg_maxgen) {
         HtProfScope ps(c, c->rs_gennames ? "resample_tail" : "resample");
-        if (c->tail_table)
-            hipLaunchKernelGGL(k_resample_tail, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
+        if (c->tail_table == 2)
+            hipLaunchKernelGGL((k_resample_tail<false, HT_TAIL_SMALL_WPS>), dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs,
+                               c->d_tail_prefix, c->d_tail_tapref, c->d_tail_taps_fast, c->d_tail_taps, c->h_tail, c->d_arena, c->arena_stride, (uint32_t)c->nframes);
+        else if (c->tail_table)
+            hipLaunchKernelGGL((k_resample_tail<true, 4>), dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAIL_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,
                                c->d_tail_tapref, c->d_tail_taps_fast, c->d_tail_taps, c->h_tail, c->d_arena, c->arena_stride, (uint32_t)c->nframes);
         else
             hipLaunchKernelGGL(k_resample_tail_f64, dim3(((uint32_t)c->nframes + 7u) & ~7u), dim3(TAILF_NT), 0, c->stream, c->d_tail_jobs, c->d_tail_prefix,

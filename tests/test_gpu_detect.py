@@ -220,12 +220,13 @@ def test_gray_in_r_entry(ctx, cascade):
     assert len(a) == 9 and a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("table", ["0", "1"], ids=["binary64-tail", "table-tail"])
+@pytest.mark.parametrize("table", ["0", "1", "2"], ids=["binary64-tail", "table-tail", "table-tail-small"])
 @pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (38, 30)])
 def test_pyramid_both_tail_kernels(w, h, table):
-    """The last generations are built by one of two tail kernels, chosen by batch size: the round-1 one (taps re-derived in
+    """The last generations are built by one of the tail kernels, chosen by batch size: the round-1 one (taps re-derived in
     registers, binary64 lerps) and the table-driven one (host tap tables, binary32 estimate + binary64 fallback, integer box
-    means).  Forced here on the same inputs: every plane equals the oracle's with either."""
+    means; compact taps in LDS, or — the small-footprint form — read from L2).  Forced here on the same inputs: every plane
+    equals the oracle's with each."""
     c = Context(options=f"rs_tailtable={table}")
     try:
         _check_pyramid(c, w, h)

@@ -91,12 +91,14 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
     dts = env.timed_rounds(block, steps, a.rounds)
     dt, spread = round_stats(dts, steps)
     total_frames = world * nf * steps * (CALLS + 1)  # every processed frame: 1 detected + 60 tracked per stream
-    for cx in ctxs[1:]:
-        cx.close()
     if rank != 0:
-        ctx.close()
+        for cx in ctxs:
+            cx.close()
         return None
-    # camshift roofline: HIP-event timing of the track kernels + the window pixels actually visited
+    # camshift roofline: HIP-event timing of the track kernels + the window pixels actually visited.  The other contexts stay
+    # alive (idle) until this leg is done, so that it launches the SAME form of k_cs_track_fused as the timed region did: with
+    # several contexts of a device on the path the library takes the 512-thread form (two workgroups per CU), whose launch — alone
+    # on the chip, as here — lasts longer than the 1024-thread form's while two of them side by side get more calls done.
     ctx.camshift_stats(nf, reset=True)
     ctx.profile(True)
     ctx.kernel_times(reset=True)
@@ -105,6 +107,8 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
     kt = ctx.kernel_times(reset=True)
     ctx.profile(False)
     px, calls = ctx.camshift_stats(nf, reset=True)
+    for cx in ctxs[1:]:
+        cx.close()
     win_px_per_call = float(px.sum()) / max(float(calls.sum()), 1.0)
     # one full-frame histogram pass + the window passes, per stream and call
     b_track = 4 * W * H + 4 * win_px_per_call
@@ -150,6 +154,10 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
                                      frac=round(own[k] / (per_launch[k] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
                              for k in per_launch},
         "track_path_hbm_frac": round(b_track * nf / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        # the same bytes against the wall clock of the timed region (detect steps included): what several launches side by side achieve
+        "track_wall_hbm_frac": round(b_track * nf * CALLS * steps / dt / 1e9 / HBM_PEAK_GBS, 5),
+        "fused_kernel_form": ("512 threads, two workgroups per CU (several contexts on the path)" if depth > 1 and not a.options
+                              else "by option / 1024 threads for a single context"),
         "track_calls_per_s_device": round(nf / (call_ms * 1e-3), 1),
         "detected": int((state["best"]["neighbors"] > 0).sum()), "alive": int((state["tracked"]["width"] > 0).sum()),
     }

@@ -269,13 +269,23 @@ struct CsRegion {
     int x0, y0, rw, rh;    // rw == 0: no region cached
 };
 
-template <bool SECOND, int NW, bool REG>
+// NW = wavefronts the rows are dealt out to, PW = wavefronts the workgroup really has (NW % PW == 0): with PW < NW a wavefront plays
+// NW / PW of them in turn (rows, partial sums, wave sums and their slots of red[] are those of the NW-wavefront workgroup), so a
+// 512-thread workgroup adds exactly what a 1024-thread one adds, in the same order — k_cs_track_fused<.., 512> below.
+template <bool SECOND, int NW, bool REG, int PW = NW>
 __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, int W, const double *lut, const CsRegion &R, int x, int y, int w, int h,
                                               double (*red)[NW], unsigned long long *fine = nullptr) {
     Mom m = {0, 0, 0, 0, 0, 0};
     CS_STAMP(fine, 0);
     const int ww = w - x, hh = h - y;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    constexpr int VPP = NW / PW;
+    static_assert(NW % PW == 0, "virtual wavefronts per physical one");
+    double vs[VPP > 1 ? VPP - 1 : 1][6];  // wave sums of the wavefronts already played (wave-uniform)
+#pragma unroll
+    for (int vi = 0; vi < VPP; vi++) {
+    const int wave = (int)(threadIdx.x >> 6) + vi * PW;
+    m = Mom{0, 0, 0, 0, 0, 0};
     // Shader-clock stamps (HT_CS_TIMELINE) of a pass over an 83 x 83 window: pixel loop 9.3 k cycles, wave sums 0.8 k, final sums
     // 1.4 k, scalar mean-shift logic 0.45 k — the pixel loop was a chain of dependent round trips (bin -> LUT -> add), made
     // sequential by per-row early exits that kept the compiler from batching the loads.  So: every load of a batch of 8 rows is
@@ -324,6 +334,14 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
             }
         }
     }
+    if (vi + 1 < VPP) {  // not the last wavefront this one plays: its wave sums wait (scalar registers) for the barrier below
+        const double vq[6] = {m.m00, m.m10, m.m01, m.m11, m.m20, m.m02};
+#pragma unroll
+        for (int k = 0; k < (SECOND ? 6 : 3); k++) vs[vi][k] = wave < nwa ? wave_sum_f64(vq[k]) : 0.0;
+    }
+    }  // vi
+    const int wave = (int)(threadIdx.x >> 6) + (VPP - 1) * PW;
+    const int nwa = min(NW, max(4, (hh + 7) >> 3));
     double v[6] = {m.m00, m.m10, m.m01, m.m11, m.m20, m.m02};
     constexpr int nv = SECOND ? 6 : 3;
     CS_STAMP(fine, 1);
@@ -333,6 +351,9 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
     for (int k = 0; k < nv; k++) {
         const double s = wave < nwa ? wave_sum_f64(v[k]) : 0.0;  // wave-uniform branch; idle waves contribute an exact 0
         if (lane == 0) red[k][wave] = s;
+#pragma unroll
+        for (int vi = 0; vi + 1 < VPP; vi++)
+            if (lane == 0) red[k][(int)(threadIdx.x >> 6) + vi * PW] = vs[vi][k];
     }
     CS_STAMP(fine, 3);
     __syncthreads();
@@ -355,13 +376,13 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
     return m;
 }
 
-template <bool SECOND, int NW>
+template <bool SECOND, int NW, int PW = NW>
 __device__ __forceinline__ Mom window_moments_any(const uint32_t *__restrict__ img, int W, const double *lut, const CsRegion &R, int x, int y, int w, int h,
                                                   double (*red)[NW], unsigned long long *fine = nullptr) {
     // workgroup-uniform: the whole window lies inside the cached region (it practically always does: the region is the search
     // window plus a margin, and a mean-shift step moves the window by a few pixels)
-    if (R.rw > 0 && x >= R.x0 && y >= R.y0 && w <= R.x0 + R.rw && h <= R.y0 + R.rh) return window_moments<SECOND, NW, true>(img, W, lut, R, x, y, w, h, red, fine);
-    return window_moments<SECOND, NW, false>(img, W, lut, R, x, y, w, h, red, fine);
+    if (R.rw > 0 && x >= R.x0 && y >= R.y0 && w <= R.x0 + R.rw && h <= R.y0 + R.rh) return window_moments<SECOND, NW, true, PW>(img, W, lut, R, x, y, w, h, red, fine);
+    return window_moments<SECOND, NW, false, PW>(img, W, lut, R, x, y, w, h, red, fine);
 }
 
 // Copies the neighbourhood of the search window (the window clamped to the frame, grown by as large a margin as `cap` pixels
@@ -532,6 +553,15 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
 // window passes from L2), the model histogram (16 KB) and the state.
 constexpr int FUSED_NT = 1024;
 constexpr int CS_REGION_CAP = 40960;  // pixels of the cached search region: 80 KB of LDS next to the 32 KB LUT and the 16 KB histogram
+// The 1024-thread form owns its CU: 128 KB of LDS and 16 wavefronts x 122 VGPRs leave no room for anything else, so the track launches
+// of several contexts (and the detect kernels of their next batches) run strictly one after the other although a call is a bandwidth
+// phase (the frame streams through the histogram) followed by a latency phase (<= 10 dependent moment passes from LDS).  The
+// 512-thread form (round 5) is half of it — 8 wavefronts, <= 128 VGPRs, a 28 KB region: 77 KB of LDS — so TWO workgroups share a CU,
+// normally at different phases of their calls, or a workgroup shares it with another batch's detect kernels.  Its wavefronts play the
+// 16 of the large form in window_moments, so both forms return the same bits.  Chosen per launch (fused_threads below): more streams
+// than CUs, or more than one context of the device on this path.
+constexpr int FUSED_NT_SMALL = 512;
+constexpr int CS_REGION_CAP_SMALL = 14336;  // 28 KB: an 83 x 83 search window + 16 px of margin is 13 225 pixels
 
 // Up to CS_SEQ_MAX successive track() calls of every stream in ONE launch (ht_camshift_track_sequence): the frame batches of the calls
 // travel as kernel arguments, a workgroup walks its stream's calls in order.  The calls of a stream depend on each other through its
@@ -559,12 +589,13 @@ struct CsFusedArgs {
 };
 typedef const CsFusedArgs __attribute__((address_space(4))) *CsFusedArgsPtr;
 
-template <bool SEQ>
-__global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFusedArgs args_by_value) {
+template <bool SEQ, int NT>
+__global__ __launch_bounds__(NT, 4) void k_cs_track_fused(const CsFusedArgs args_by_value) {
+    constexpr int NWV = FUSED_NT / 64;  // wavefronts the moment passes are laid out for (window_moments), whatever NT is
     extern __shared__ __attribute__((aligned(16))) uint8_t cs_dyn[];  // [region_cap] u16 bins of the cached search region
     __shared__ double lut[4096];
     __shared__ uint32_t h[4096];
-    __shared__ double red[6][FUSED_NT / 64];
+    __shared__ double red[6][NWV];
     __shared__ int s_sw[4];
     (void)args_by_value;
     CsFusedArgsPtr ka = (CsFusedArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
@@ -587,14 +618,14 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFusedArgs a
     unsigned long long *stamps = nullptr;
 #endif
     CS_STAMP(stamps, 0);
-    for (int i = threadIdx.x; i < 4096; i += FUSED_NT) h[i] = 0;
+    for (int i = threadIdx.x; i < 4096; i += NT) h[i] = 0;
     if (threadIdx.x < 4) s_sw[threadIdx.x] = st.sw[threadIdx.x];
     __syncthreads();
     // the search region (search window + margin) is cached in LDS as histogram bins for the moment passes; when rows are whole
     // 16-byte groups the histogram pass below stashes it on the way (the frame is read exactly once), otherwise a separate copy
     // pass after the LUT does (cs_cache_region)
     uint16_t *const rbins = reinterpret_cast<uint16_t *>(cs_dyn);
-    const int qpr = W >> 2, rpi = qpr > 0 ? FUSED_NT / qpr : 0;  // 16-byte groups per row, rows per sweep of the workgroup
+    const int qpr = W >> 2, rpi = qpr > 0 ? NT / qpr : 0;  // 16-byte groups per row, rows per sweep of the workgroup
     const bool rows2d = (W & 3) == 0 && rpi >= 1;
     CsRegion R = {rbins, 0, 0, 0, 0};
     if (rows2d) R = cs_region_rect(W, H, s_sw, rbins, region_cap);
@@ -636,13 +667,13 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFusedArgs a
         } else {
             const uint32_t nquad = npix / 4;
             // 8 independent 16-byte loads per thread in flight (128 KB per workgroup): one workgroup has a whole frame to pull
-            for (uint32_t i0 = threadIdx.x; i0 < nquad; i0 += 8 * FUSED_NT) {
+            for (uint32_t i0 = threadIdx.x; i0 < nquad; i0 += 8 * NT) {
                 uint4 p[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) p[u] = img4[min(i0 + u * FUSED_NT, nquad - 1)];  // clamped address, masked below
+                for (int u = 0; u < 8; u++) p[u] = img4[min(i0 + u * NT, nquad - 1)];  // clamped address, masked below
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
-                    const bool on = i0 + u * FUSED_NT < nquad;
+                    const bool on = i0 + u * NT < nquad;
                     const uint32_t b0 = cs_bin(p[u].x), b1 = cs_bin(p[u].y), b2 = cs_bin(p[u].z), b3 = cs_bin(p[u].w);
                     const bool flat = (b0 == b1) && (b2 == b3) && (b0 == b2);
                     hist_add_wave(h, b0, flat ? 4u : 1u, on);
@@ -654,14 +685,15 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFusedArgs a
                 }
             }
             const uint32_t *img1 = reinterpret_cast<const uint32_t *>(frame);
-            for (uint32_t i = nquad * 4 + threadIdx.x; i < npix; i += FUSED_NT) atomicAdd(&h[cs_bin(img1[i])], 1u);  // < 4 pixels
+            for (uint32_t i = nquad * 4 + threadIdx.x; i < npix; i += NT) atomicAdd(&h[cs_bin(img1[i])], 1u);  // < 4 pixels
         }
     }
     __syncthreads();
     CS_STAMP(stamps, 1);
     {  // getWeights, camshift.js:314-330
         const uint4 *model4 = reinterpret_cast<const uint4 *>(st.model);
-        const int i4 = threadIdx.x;  // 1024 threads x 4 bins
+#pragma unroll
+        for (int i4 = threadIdx.x; i4 < 1024; i4 += NT) {  // 4 bins per thread and round (one round with 1024 threads)
         const uint4 m = model4[i4];
         const uint4 cv = reinterpret_cast<const uint4 *>(h)[i4];
         if (dbg_hist) reinterpret_cast<uint4 *>(dbg_hist + (size_t)s * 4096)[i4] = cv;
@@ -675,16 +707,17 @@ __global__ __launch_bounds__(FUSED_NT) void k_cs_track_fused(const CsFusedArgs a
             }
             lut[i4 * 4 + q] = p;
         }
+        }
     }
     CS_STAMP(stamps, 2);
     // the search region: the frame went through this CU a moment ago, but not into any cache that would still hold it
-    if (!rows2d) R = cs_cache_region<FUSED_NT>(reinterpret_cast<const uint32_t *>(frame), W, H, s_sw, rbins, region_cap);
+    if (!rows2d) R = cs_cache_region<NT>(reinterpret_cast<const uint32_t *>(frame), W, H, s_sw, rbins, region_cap);
     __syncthreads();  // LUT and region complete
     CS_STAMP(stamps, 3);
     const uint32_t *img = reinterpret_cast<const uint32_t *>(frame);
     ht_cs_trackobj *const out = ka->out;
     meanshift_body(W, H, s_sw, st, ka->calc_angles, ka->max_it, out ? out + (size_t)call * ka->out_call_stride + s : nullptr, stamps, true,
-                   [&](int x, int y, int w, int h) { return window_moments_any<true, FUSED_NT / 64>(img, W, lut, R, x, y, w, h, red); });
+                   [&](int x, int y, int w, int h) { return window_moments_any<true, NWV, NT / 64>(img, W, lut, R, x, y, w, h, red); });
 #ifdef HT_CS_TIMELINE
     if (threadIdx.x == 0 && dbg_hist)
         for (int i = 0; i < 30; i++) reinterpret_cast<unsigned long long *>(dbg_hist + (size_t)s * 4096 + 4032)[i] = s_stamps[i];
@@ -878,6 +911,7 @@ struct ClusterGate {
     struct Dev {
         hipEvent_t last = nullptr;            // recorded after the most recent cluster launch (only while `multi`)
         std::vector<const ht_ctx *> users;    // contexts that have launched a cluster grid on this device
+        std::vector<const ht_ctx *> fused;    // contexts that have launched k_cs_track_fused on this device (fused_threads)
         bool multi = false;                   // more than one user: every launch waits for `last` and records it
     };
     std::map<int, Dev> dev;
@@ -896,6 +930,8 @@ void ht_cluster_gate_forget(const ht_ctx *c) {
     if (it == gate.dev.end()) return;
     auto &u = it->second.users;
     u.erase(std::remove(u.begin(), u.end(), c), u.end());
+    auto &fu = it->second.fused;
+    fu.erase(std::remove(fu.begin(), fu.end(), c), fu.end());
     if (u.size() <= 1 && it->second.multi) {
         // back to one user: its recorded grids are ordered by its own stream from here on
         it->second.multi = false;
@@ -1029,6 +1065,19 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
     return HT_OK;
 }
 
+// Threads per workgroup of k_cs_track_fused for a launch of n streams: option cs_fused_nt, else the small form when the launch has
+// more workgroups than the device has CUs (all of them resident at once, two per CU) or when another live context of the device has
+// used this path (their launches then share the CUs instead of queueing behind each other), else the large form (one stream per CU
+// with the whole CU to itself: the lowest latency for a single context).  Both forms return the same bits.
+static int fused_threads(ht_ctx *c, int n) {
+    if (c->cs_fused_nt == FUSED_NT || c->cs_fused_nt == FUSED_NT_SMALL) return c->cs_fused_nt;
+    ClusterGate &gate = cluster_gate();
+    std::lock_guard<std::mutex> lk(gate.mu);
+    auto &fu = gate.dev[c->device].fused;
+    if (std::find(fu.begin(), fu.end(), c) == fu.end()) fu.push_back(c);
+    return (n > c->num_cus || fu.size() >= 2) ? FUSED_NT_SMALL : FUSED_NT;
+}
+
 // one track() call of streams [first, first + n) on frames[0..n): histogram pass + mean-shift, results to d_out[0..n)
 // done_flags (pinned, n words) / done_seq: completion marks for an enqueue-only call — written by the cluster kernel if that path is
 // taken (*flags_used = true), otherwise the caller records its event.
@@ -1036,7 +1085,7 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
                               ht_cs_trackobj *d_out, uint32_t *done_flags = nullptr, uint32_t done_seq = 0u, bool *flags_used = nullptr) {
     const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
     if (!c->cs_attr_set) {  // the cached search region needs more than the default 64 KB of LDS per workgroup (per context = per device)
-        HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
+        HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused<false, FUSED_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
         HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_meanshift), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
         c->cs_attr_set = true;
     }
@@ -1050,7 +1099,12 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
         ka.ncalls = 1, ka.W = c->W, ka.H = c->H, ka.npix = npix, ka.frame_stride = frame_stride, ka.states = c->d_cs, ka.first = first;
         ka.calc_angles = calc_angles, ka.max_it = c->dbg_cs_iters, ka.region_cap = c->cs_region_cap, ka.out = d_out, ka.out_call_stride = 0u;
         ka.dbg_hist = c->cs_keep_hist ? c->d_cs_hist : nullptr;
-        hipLaunchKernelGGL(k_cs_track_fused<false>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, ka);
+        if (fused_threads(c, n) == FUSED_NT_SMALL) {
+            ka.region_cap = std::min(ka.region_cap, CS_REGION_CAP_SMALL);
+            hipLaunchKernelGGL((k_cs_track_fused<false, FUSED_NT_SMALL>), dim3(n), dim3(FUSED_NT_SMALL), (size_t)CS_REGION_CAP_SMALL * 2, c->stream, ka);
+        } else {
+            hipLaunchKernelGGL((k_cs_track_fused<false, FUSED_NT>), dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, ka);
+        }
         HT_HIP(c, hipGetLastError());
         c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;
         c->cs_last_hist = c->d_cs_hist;
@@ -1209,10 +1263,11 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
     if (n >= c->cs_fused_min_streams && c->cs_seq_fused) {
         // one launch per CS_SEQ_MAX calls: every workgroup walks its stream's calls on its own (see k_cs_track_fused)
         if (!c->cs_seq_attr_set) {
-            HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
+            HT_HIP(c, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_track_fused<true, FUSED_NT>), hipFuncAttributeMaxDynamicSharedMemorySize, CS_REGION_CAP * 2));
             c->cs_seq_attr_set = true;
         }
         const uint32_t npix = (uint32_t)((size_t)c->W * c->H);
+        const bool small = fused_threads(c, n) == FUSED_NT_SMALL;
         for (int k0 = 0; k0 < ncalls; k0 += CS_SEQ_MAX) {
             const int kc = std::min(CS_SEQ_MAX, ncalls - k0);
             CsFusedArgs ka;
@@ -1223,7 +1278,12 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
             ka.out = c->d_cs_seq_out + (out_all ? (size_t)k0 * n : 0), ka.out_call_stride = out_all ? (uint32_t)n : 0u;
             ka.dbg_hist = c->cs_keep_hist ? c->d_cs_hist : nullptr;
             HtProfScope ps(c, "cs_track");
-            hipLaunchKernelGGL(k_cs_track_fused<true>, dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, ka);
+            if (small) {
+                ka.region_cap = std::min(ka.region_cap, CS_REGION_CAP_SMALL);
+                hipLaunchKernelGGL((k_cs_track_fused<true, FUSED_NT_SMALL>), dim3(n), dim3(FUSED_NT_SMALL), (size_t)CS_REGION_CAP_SMALL * 2, c->stream, ka);
+            } else {
+                hipLaunchKernelGGL((k_cs_track_fused<true, FUSED_NT>), dim3(n), dim3(FUSED_NT), (size_t)CS_REGION_CAP * 2, c->stream, ka);
+            }
             HT_HIP(c, hipGetLastError());
         }
         c->cs_last_first = first, c->cs_last_n = n, c->cs_last_chunks = c->cs_keep_hist ? 1 : 0;

@@ -297,6 +297,7 @@ static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) 
         else if (key == "deep_grid") c->deep_grid = std::max(1, iv);
         else if (key == "split") c->opt_split = std::max(1, iv);
         else if (key == "cs_fused_min") c->cs_fused_min_streams = std::max(1, iv);
+        else if (key == "cs_fused_nt") c->cs_fused_nt = iv;
         else if (key == "cs_keep_hist") c->cs_keep_hist = iv != 0;
         else if (key == "cs_seq_fused") c->cs_seq_fused = iv != 0;
         else if (key == "cs_cluster") c->cs_cluster = iv != 0;

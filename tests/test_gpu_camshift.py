@@ -38,11 +38,15 @@ def _write_parity():
 atexit.register(_write_parity)
 
 
-@pytest.fixture(scope="module", params=["chunked", "fused"])
+SCHEDULES = {"chunked": "cs_fused_min=1000000", "fused": "cs_fused_min=1,cs_fused_nt=1024", "fused512": "cs_fused_min=1,cs_fused_nt=512"}
+
+
+@pytest.fixture(scope="module", params=list(SCHEDULES))
 def ctx(request):
-    """every test of this module runs on both camshift schedules: chunk histograms + one mean-shift workgroup per stream (few
-    streams), and the single-launch kernel that is chosen for >= 192 streams (forced here with option cs_fused_min=1)"""
-    c = Context(options="cs_fused_min=1" if request.param == "fused" else "cs_fused_min=1000000")
+    """every test of this module runs on the camshift schedules: chunk histograms + one mean-shift workgroup per stream (few
+    streams), and the single-launch kernel that is chosen for >= 192 streams (forced here with option cs_fused_min=1) in its
+    1024-thread form (one stream owns a CU) and its 512-thread form (two workgroups per CU)"""
+    c = Context(options=SCHEDULES[request.param])
     yield c
     c.close()
 
@@ -141,7 +145,7 @@ def test_batch_of_streams_vs_oracle(ctx):
 
 
 @pytest.mark.parametrize("w,h,n", [(1920, 1080, 1), (641, 363, 3), (61, 45, 2)], ids=["1080p-1stream", "odd-641x363", "tiny-61x45"])
-@pytest.mark.parametrize("fused", [False, True], ids=["chunked", "fused"])
+@pytest.mark.parametrize("fused", list(SCHEDULES))
 def test_frame_sizes_and_chunking(w, h, n, fused):
     """The histogram pass cuts a frame into chunk histograms (127 for one 1080p stream, 1 for a tiny frame) and handles
     pixel counts that are not multiples of 4; the mean-shift kernel adds the chunks.  Same answers as the oracle."""
@@ -152,7 +156,7 @@ def test_frame_sizes_and_chunking(w, h, n, fused):
         cx, cy = w // 2 + 3 * s, h // 2 - 2 * s
         seqs.append([synth.blob_frame(w, h, cx + k, cy + k // 2, a, b, (4, 3, 5), (200, 60, 40), seed=77 + 13 * s + k) for k in range(steps)])
         rects.append((cx - a, cy - b, 2 * a, 2 * b))
-    c = Context(options="cs_fused_min=1" if fused else "cs_fused_min=1000000")
+    c = Context(options=SCHEDULES[fused])
     try:
         c.set_geometry(w, h, n)
         c.camshift_reserve(n)

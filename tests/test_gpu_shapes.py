@@ -247,13 +247,60 @@ def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
             d.free()
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["chunked", "fused"])
+def test_fused_track_kernel_forms_return_the_same_bits(cascade):
+    """k_cs_track_fused exists in a 1024-thread form (one stream owns a CU) and a 512-thread form (two workgroups per CU, chosen when a
+    launch has more streams than the device has CUs or when a second context of the device tracks on this path: their launches then
+    share the CUs).  The small form's wavefronts play the sixteen of the large one, so every track object is identical to the last
+    bit of the angle — forced forms on the C3 shape, then the automatic choice with one and with two contexts alive."""
+    from hipmem import DeviceArray
+
+    w, h, n, nv, calls = 320, 240, 256, 4, 12
+    vers = _c3_streams(n, w, h, nv)
+    rects = [(w // 4 + (f % 7), h // 4 + (f % 5), w // 3, h // 3) for f in range(n)]
+    ctxs = [Context(options="cs_fused_nt=1024"), Context(options="cs_fused_nt=512"), Context(), Context()]
+    dev = [DeviceArray(vers[v]) for v in range(nv)]
+    try:
+        outs = []
+        for c in ctxs:
+            c.set_geometry(w, h, n)
+            c.bind_device(dev[0].ptr, n)
+            c.camshift_reserve(n)
+            c.camshift_init(rects)
+        for c in ctxs[:3]:  # the third one chooses by itself: nobody else has used the path without an explicit form
+            outs.append(c.camshift_track_sequence([dev[(k + 1) % nv].ptr for k in range(calls)], n, calc_angles=True, fetch="all"))
+        # two contexts on the automatic rule with their sequences in flight at the same time
+        for c in ctxs[2:]:
+            c.bind_device(dev[0].ptr, n)
+            c.camshift_init(rects)
+        for c in ctxs[2:]:
+            assert c.camshift_track_sequence([dev[(k + 1) % nv].ptr for k in range(calls)], n, calc_angles=True, fetch="none", keep_all=True) is None
+        for c in ctxs[2:]:
+            outs.append(c.camshift_sequence_collect(n, calls, fetch="all"))
+        # and one call at a time
+        c = ctxs[1]
+        c.bind_device(dev[0].ptr, n)
+        c.camshift_init(rects)
+        for k in range(3):
+            c.bind_device(dev[(k + 1) % nv].ptr, n)
+            assert c.camshift_track(n, calc_angles=True).tobytes() == outs[0][k].tobytes(), k
+        for i, o in enumerate(outs[1:]):
+            assert o.tobytes() == outs[0].tobytes(), i + 1
+        moved = sum(int(outs[0][calls - 1][f]["sw_x"]) != rects[f][0] for f in range(n))
+        assert moved > n // 2  # the trackers did something
+    finally:
+        for c in ctxs:
+            c.close()
+        for d in dev:
+            d.free()
+
+
+@pytest.mark.parametrize("fused", [0, 1024, 512], ids=["chunked", "fused", "fused512"])
 def test_camshift_histograms_bin_for_bin(fused):
     """camshift.Histogram (camshift.js:49-72): the model histogram of initTracker and the full-frame histogram of track(),
     read back from the device, equal the oracle's in every one of the 4096 bins — incl. a rect reaching outside the frame
     (transparent black -> bin 0), an odd pixel count, and a frame cut into many chunk histograms; on both schedules (the
     single-launch kernel keeps its histogram in LDS and only writes it out with option cs_keep_hist)."""
-    opts = f"cs_fused_min={1 if fused else 1000000},cs_keep_hist=1"
+    opts = f"cs_fused_min={1 if fused else 1000000},cs_keep_hist=1" + (f",cs_fused_nt={fused}" if fused else "")
     for (w, h, rect) in [(320, 240, (100, 60, 90, 80)), (321, 243, (-10, -5, 60, 70)), (1280, 720, (1200, 650, 200, 200))]:
         a = synth.blob_frame(w, h, w // 2, h // 2, w // 6, h // 8, (4, 3, 5), (200, 60, 40), seed=5)
         b = synth.blob_frame(w, h, w // 2 + 3, h // 2 + 2, w // 6, h // 8, (4, 3, 5), (200, 60, 40), seed=6)

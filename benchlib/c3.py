@@ -95,20 +95,40 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
         for cx in ctxs:
             cx.close()
         return None
-    # camshift roofline: HIP-event timing of the track kernels + the window pixels actually visited.  The other contexts stay
-    # alive (idle) until this leg is done, so that it launches the SAME form of k_cs_track_fused as the timed region did: with
-    # several contexts of a device on the path the library takes the 512-thread form (two workgroups per CU), whose launch — alone
-    # on the chip, as here — lasts longer than the 1024-thread form's while two of them side by side get more calls done.
+    # Which form of k_cs_track_fused did the steady state launch (the library takes the 512-thread form, two workgroups per CU,
+    # when another context of the device has work in flight at launch time)?  One more block, untimed, with the profiling timers on
+    # in every context: the timer's name tells the form.
+    for cx in ctxs:
+        cx.profile(True)
+        cx.kernel_times(reset=True)
+    block(2 * depth)
+    forms = {}
+    for cx in ctxs:
+        for k, v in cx.kernel_times(reset=True).items():
+            if k.startswith("cs_track"):
+                forms[k] = forms.get(k, 0) + int(v["launches"])
+        cx.profile(False)
+    form = 512 if forms.get("cs_track_512", 0) > forms.get("cs_track", 0) else 1024
+    for cx in ctxs[1:]:
+        cx.close()
+    # camshift roofline: HIP-event timing of the track kernel — THAT form, alone on the chip (a context of its own with the form
+    # forced: the launch's own duration; side by side two launches of the small form get more calls done than this says) — and
+    # the window pixels actually visited
+    ctx.close()
+    ctx = Context(device=local, options=",".join(x for x in (a.options, f"cs_fused_nt={form}") if x))
+    ctx.set_geometry(W, H, nf)
+    ctx.bind_device(dev_vers[0].data_ptr(), nf, W * H * 4)
+    ctx.camshift_reserve(nf)
+    ctx.camshift_init(state["rects"])
+    ctx.camshift_track_sequence(seq_ptrs, nf, calc_angles=True)  # warm
     ctx.camshift_stats(nf, reset=True)
     ctx.profile(True)
     ctx.kernel_times(reset=True)
     ctx.camshift_init(state["rects"])
     ctx.camshift_track_sequence(seq_ptrs, nf, calc_angles=True)
-    kt = ctx.kernel_times(reset=True)
+    kt = {("cs_track" if k == "cs_track_512" else k): v for k, v in ctx.kernel_times(reset=True).items()}
     ctx.profile(False)
     px, calls = ctx.camshift_stats(nf, reset=True)
-    for cx in ctxs[1:]:
-        cx.close()
     win_px_per_call = float(px.sum()) / max(float(calls.sum()), 1.0)
     # one full-frame histogram pass + the window passes, per stream and call
     b_track = 4 * W * H + 4 * win_px_per_call
@@ -156,8 +176,9 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
         "track_path_hbm_frac": round(b_track * nf / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         # the same bytes against the wall clock of the timed region (detect steps included): what several launches side by side achieve
         "track_wall_hbm_frac": round(b_track * nf * CALLS * steps / dt / 1e9 / HBM_PEAK_GBS, 5),
-        "fused_kernel_form": ("512 threads, two workgroups per CU (several contexts on the path)" if depth > 1 and not a.options
-                              else "by option / 1024 threads for a single context"),
+        "fused_kernel_form": {"threads": form, "launches_in_probe_block": forms,
+                              "note": "k_cs_track_fused<SEQ, 512> = two workgroups per CU, taken when another context of the device "
+                                      "has work in flight at launch time; roofline = that form's launch alone on the chip"},
         "track_calls_per_s_device": round(nf / (call_ms * 1e-3), 1),
         "detected": int((state["best"]["neighbors"] > 0).sum()), "alive": int((state["tracked"]["width"] > 0).sum()),
     }

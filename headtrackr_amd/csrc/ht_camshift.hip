@@ -1066,16 +1066,28 @@ extern "C" ht_status ht_camshift_init_batch(ht_ctx *c, int32_t first, int32_t n,
 }
 
 // Threads per workgroup of k_cs_track_fused for a launch of n streams: option cs_fused_nt, else the small form when the launch has
-// more workgroups than the device has CUs (all of them resident at once, two per CU) or when another live context of the device has
-// used this path (their launches then share the CUs instead of queueing behind each other), else the large form (one stream per CU
-// with the whole CU to itself: the lowest latency for a single context).  Both forms return the same bits.
+// more workgroups than the device has CUs (all of them resident at once, two per CU) or when ANOTHER live context of the device that
+// uses this path has work in flight right now (hipStreamQuery on its stream: no packet, ~1 us) — its track launch, or the detect
+// kernels of its next batch, then share the CUs with this launch instead of queueing behind it —, else the large form (one stream per
+// CU with the whole CU to itself: the lowest latency, and the right choice whenever nothing else wants the chip: measured on C3 with
+// TWO steps in flight, where a context's track launch never meets the other's, the small form costs 18 %).  Both forms return the
+// same bits.
 static int fused_threads(ht_ctx *c, int n) {
     if (c->cs_fused_nt == FUSED_NT || c->cs_fused_nt == FUSED_NT_SMALL) return c->cs_fused_nt;
-    ClusterGate &gate = cluster_gate();
-    std::lock_guard<std::mutex> lk(gate.mu);
-    auto &fu = gate.dev[c->device].fused;
-    if (std::find(fu.begin(), fu.end(), c) == fu.end()) fu.push_back(c);
-    return (n > c->num_cus || fu.size() >= 2) ? FUSED_NT_SMALL : FUSED_NT;
+    bool other_busy = false;
+    {
+        ClusterGate &gate = cluster_gate();
+        std::lock_guard<std::mutex> lk(gate.mu);  // ht_destroy forgets a context under this lock before it destroys its stream
+        auto &fu = gate.dev[c->device].fused;
+        if (std::find(fu.begin(), fu.end(), c) == fu.end()) fu.push_back(c);
+        for (const ht_ctx *o : fu)
+            if (o != c && o->stream && hipStreamQuery(o->stream) == hipErrorNotReady) {
+                other_busy = true;
+                break;
+            }
+        (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error: keep it out of the launch checks that follow
+    }
+    return (n > c->num_cus || other_busy) ? FUSED_NT_SMALL : FUSED_NT;
 }
 
 // one track() call of streams [first, first + n) on frames[0..n): histogram pass + mean-shift, results to d_out[0..n)
@@ -1092,14 +1104,15 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
     // enough streams to keep (most of) the 256 CUs busy with one workgroup each: the fused single-launch kernel; fewer streams
     // (a handful of large feeds): chunk histograms from every CU, then one mean-shift workgroup per stream
     if (n >= c->cs_fused_min_streams) {
-        HtProfScope ps(c, "cs_track");
+        const bool small = fused_threads(c, n) == FUSED_NT_SMALL;
+        HtProfScope ps(c, small ? "cs_track_512" : "cs_track");  // the timer's name tells the form
         CsFusedArgs ka;
         std::memset(&ka, 0, sizeof(ka));
         ka.flist.p[0] = frames;
         ka.ncalls = 1, ka.W = c->W, ka.H = c->H, ka.npix = npix, ka.frame_stride = frame_stride, ka.states = c->d_cs, ka.first = first;
         ka.calc_angles = calc_angles, ka.max_it = c->dbg_cs_iters, ka.region_cap = c->cs_region_cap, ka.out = d_out, ka.out_call_stride = 0u;
         ka.dbg_hist = c->cs_keep_hist ? c->d_cs_hist : nullptr;
-        if (fused_threads(c, n) == FUSED_NT_SMALL) {
+        if (small) {
             ka.region_cap = std::min(ka.region_cap, CS_REGION_CAP_SMALL);
             hipLaunchKernelGGL((k_cs_track_fused<false, FUSED_NT_SMALL>), dim3(n), dim3(FUSED_NT_SMALL), (size_t)CS_REGION_CAP_SMALL * 2, c->stream, ka);
         } else {
@@ -1277,7 +1290,7 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
             ka.calc_angles = calc_angles, ka.max_it = c->dbg_cs_iters, ka.region_cap = c->cs_region_cap;
             ka.out = c->d_cs_seq_out + (out_all ? (size_t)k0 * n : 0), ka.out_call_stride = out_all ? (uint32_t)n : 0u;
             ka.dbg_hist = c->cs_keep_hist ? c->d_cs_hist : nullptr;
-            HtProfScope ps(c, "cs_track");
+            HtProfScope ps(c, small ? "cs_track_512" : "cs_track");
             if (small) {
                 ka.region_cap = std::min(ka.region_cap, CS_REGION_CAP_SMALL);
                 hipLaunchKernelGGL((k_cs_track_fused<true, FUSED_NT_SMALL>), dim3(n), dim3(FUSED_NT_SMALL), (size_t)CS_REGION_CAP_SMALL * 2, c->stream, ka);

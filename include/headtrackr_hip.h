@@ -65,7 +65,8 @@ typedef struct ht_config {
                              * schedules that produce IDENTICAL results; an unknown key fails ht_create with HT_ERR_INVALID.
                              *   cs_fused_min=N       streams per call from which camshift runs as one launch (default 192)
                              *   cs_fused_nt=512|1024 threads per workgroup of that launch (0 = per launch: 512 — two workgroups per CU — when it has more
-                             *                        streams than the device has CUs or another context of the device tracks on this path, else 1024)
+                             *                        streams than the device has CUs or another context of the device that tracks on this path has
+                             *                        work in flight at launch time, else 1024)
                              *   cs_seq_fused=0|1     track sequences inside one launch (1)       cs_keep_hist=1   keep histograms for ht_camshift_debug_hist
                              *   cs_cluster=0|1, cs_cluster_min_px=N, cs_region=N                 cluster / LDS-region paths of the few-stream schedule
                              *   cs_barrier_budget=N  shader-clock cycles a cluster exchange may wait before the call fails with HT_ERR_STATE

@@ -249,9 +249,10 @@ def test_c3_shape_256_streams_60_calls_vs_oracle(cascade):
 
 def test_fused_track_kernel_forms_return_the_same_bits(cascade):
     """k_cs_track_fused exists in a 1024-thread form (one stream owns a CU) and a 512-thread form (two workgroups per CU, chosen when a
-    launch has more streams than the device has CUs or when a second context of the device tracks on this path: their launches then
-    share the CUs).  The small form's wavefronts play the sixteen of the large one, so every track object is identical to the last
-    bit of the angle — forced forms on the C3 shape, then the automatic choice with one and with two contexts alive."""
+    launch has more streams than the device has CUs or when another context of the device that tracks on this path has work in
+    flight at launch time: the launches then share the CUs).  The small form's wavefronts play the sixteen of the large one, so
+    every track object is identical to the last bit of the angle — forced forms on the C3 shape, then the automatic choice with a
+    context on its own and with two contexts' sequences in flight at the same time."""
     from hipmem import DeviceArray
 
     w, h, n, nv, calls = 320, 240, 256, 4, 12
@@ -266,7 +267,7 @@ def test_fused_track_kernel_forms_return_the_same_bits(cascade):
             c.bind_device(dev[0].ptr, n)
             c.camshift_reserve(n)
             c.camshift_init(rects)
-        for c in ctxs[:3]:  # the third one chooses by itself: nobody else has used the path without an explicit form
+        for c in ctxs[:3]:  # the third one chooses by itself (every call here is collected before the next context starts)
             outs.append(c.camshift_track_sequence([dev[(k + 1) % nv].ptr for k in range(calls)], n, calc_angles=True, fetch="all"))
         # two contexts on the automatic rule with their sequences in flight at the same time
         for c in ctxs[2:]:

@@ -88,6 +88,8 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
             step(i)
         drain()
 
+    for cx in ctxs:
+        cx.kernel_times(reset=True)  # the per-form launch counters restart with the timed region
     dts = env.timed_rounds(block, steps, a.rounds)
     dt, spread = round_stats(dts, steps)
     total_frames = world * nf * steps * (CALLS + 1)  # every processed frame: 1 detected + 60 tracked per stream
@@ -95,20 +97,15 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
         for cx in ctxs:
             cx.close()
         return None
-    # Which form of k_cs_track_fused did the steady state launch (the library takes the 512-thread form, two workgroups per CU,
-    # when another context of the device has work in flight at launch time)?  One more block, untimed, with the profiling timers on
-    # in every context: the timer's name tells the form.
-    for cx in ctxs:
-        cx.profile(True)
-        cx.kernel_times(reset=True)
-    block(2 * depth)
+    # Which form of k_cs_track_fused did the timed region launch (the library takes the 512-thread form, two workgroups per CU, when
+    # another context of the device has work in flight at launch time)?  The library counts the launches per form (pseudo-timers of
+    # ht_kernel_times, reset before the timed region).
     forms = {}
     for cx in ctxs:
         for k, v in cx.kernel_times(reset=True).items():
-            if k.startswith("cs_track"):
-                forms[k] = forms.get(k, 0) + int(v["launches"])
-        cx.profile(False)
-    form = 512 if forms.get("cs_track_512", 0) > forms.get("cs_track", 0) else 1024
+            if k.startswith("cs_fused_launches_"):
+                forms[k[len("cs_fused_launches_"):]] = forms.get(k[len("cs_fused_launches_"):], 0) + int(v["launches"])
+    form = 512 if forms.get("512", 0) > forms.get("1024", 0) else 1024
     for cx in ctxs[1:]:
         cx.close()
     # camshift roofline: HIP-event timing of the track kernel — THAT form, alone on the chip (a context of its own with the form
@@ -176,9 +173,9 @@ def c3_bench(env, a, steps, warmup, cpu_seconds=0.0):
         "track_path_hbm_frac": round(b_track * nf / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         # the same bytes against the wall clock of the timed region (detect steps included): what several launches side by side achieve
         "track_wall_hbm_frac": round(b_track * nf * CALLS * steps / dt / 1e9 / HBM_PEAK_GBS, 5),
-        "fused_kernel_form": {"threads": form, "launches_in_probe_block": forms,
-                              "note": "k_cs_track_fused<SEQ, 512> = two workgroups per CU, taken when another context of the device "
-                                      "has work in flight at launch time; roofline = that form's launch alone on the chip"},
+        "fused_kernel_form": {"roofline_measured_on_threads": form, "launches_in_timed_region": forms,
+                              "note": "k_cs_track_fused<SEQ, 512> = two workgroups per CU, taken per launch when another context of "
+                                      "the device has work in flight; roofline = the majority form's launch alone on the chip"},
         "track_calls_per_s_device": round(nf / (call_ms * 1e-3), 1),
         "detected": int((state["best"]["neighbors"] > 0).sum()), "alive": int((state["tracked"]["width"] > 0).sum()),
     }

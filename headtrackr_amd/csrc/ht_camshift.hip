@@ -1106,6 +1106,7 @@ static ht_status launch_track(ht_ctx *c, const uint8_t *frames, size_t frame_str
     if (n >= c->cs_fused_min_streams) {
         const bool small = fused_threads(c, n) == FUSED_NT_SMALL;
         HtProfScope ps(c, small ? "cs_track_512" : "cs_track");  // the timer's name tells the form
+        c->cs_fused_launches[small ? 1 : 0]++;
         CsFusedArgs ka;
         std::memset(&ka, 0, sizeof(ka));
         ka.flist.p[0] = frames;
@@ -1291,6 +1292,7 @@ extern "C" ht_status ht_camshift_track_sequence(ht_ctx *c, int32_t first, int32_
             ka.out = c->d_cs_seq_out + (out_all ? (size_t)k0 * n : 0), ka.out_call_stride = out_all ? (uint32_t)n : 0u;
             ka.dbg_hist = c->cs_keep_hist ? c->d_cs_hist : nullptr;
             HtProfScope ps(c, small ? "cs_track_512" : "cs_track");
+            c->cs_fused_launches[small ? 1 : 0]++;
             if (small) {
                 ka.region_cap = std::min(ka.region_cap, CS_REGION_CAP_SMALL);
                 hipLaunchKernelGGL((k_cs_track_fused<true, FUSED_NT_SMALL>), dim3(n), dim3(FUSED_NT_SMALL), (size_t)CS_REGION_CAP_SMALL * 2, c->stream, ka);

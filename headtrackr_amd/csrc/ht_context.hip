@@ -1382,8 +1382,19 @@ extern "C" ht_status ht_kernel_times(ht_ctx *c, ht_kernel_time *out, int32_t *n,
         }
         k++;
     }
+    // which form of k_cs_track_fused the launches took (chosen per launch, ht_camshift.hip): counted with profiling on or off
+    static const char *const form_names[2] = {"cs_fused_launches_1024", "cs_fused_launches_512"};
+    for (int f = 0; f < 2; f++) {
+        if (!c->cs_fused_launches[f]) continue;
+        if (out && k < cap) {
+            std::memset(&out[k], 0, sizeof(ht_kernel_time));
+            std::strncpy(out[k].name, form_names[f], sizeof(out[k].name) - 1);
+            out[k].launches = c->cs_fused_launches[f];
+        }
+        k++;
+    }
     *n = k;
-    if (reset) c->timers.clear();
+    if (reset) c->timers.clear(), c->cs_fused_launches[0] = c->cs_fused_launches[1] = 0;
     return HT_OK;
 }
 

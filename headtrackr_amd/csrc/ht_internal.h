@@ -386,6 +386,8 @@ struct ht_ctx {
     uint32_t *h_cs_err = nullptr;      // pinned copy, fetched with every result read-back
     long long cs_barrier_budget = 1ll << 28;  // shader-clock cycles a workgroup waits at one cluster barrier (option cs_barrier_budget)
     int num_cus = 256;                 // hipDeviceProp_t::multiProcessorCount: sizes the cluster of k_cs_meanshift_cluster
+    uint32_t cs_fused_launches[2] = {0, 0};  // k_cs_track_fused launches in the 1024- / 512-thread form since the last ht_kernel_times(reset): reported there as
+                                            // the pseudo-timers cs_fused_launches_1024 / _512 (ms = 0), profiling on or off
     int cs_fused_nt = 0;             // option cs_fused_nt=512|1024: threads per workgroup of k_cs_track_fused (0: chosen per launch, ht_camshift.hip fused_threads)
     int cs_fused_min_streams = 192;  // >= this many streams per call: k_cs_track_fused (option cs_fused_min)
     bool cs_seq_attr_set = false;

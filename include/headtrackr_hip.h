@@ -279,10 +279,12 @@ int32_t ht_device_count(void);
 
 /* on != 0: bracket every kernel of subsequent ht_detect_* / camshift calls with HIP events on the ctx stream. */
 ht_status ht_profile(ht_ctx *ctx, int32_t on);
-/* Device times accumulated since profiling was switched on (or last reset); *n in: capacity, out: entries. */
+/* Device times accumulated since profiling was switched on (or last reset); *n in: capacity, out: entries.  Profiling on or off, the
+ * entries cs_fused_launches_1024 / cs_fused_launches_512 (ms = 0) count the single-launch camshift kernel's launches per form since the
+ * last reset (the form is chosen per launch, option cs_fused_nt). */
 ht_status ht_kernel_times(ht_ctx *ctx, ht_kernel_time *out, int32_t *n, int32_t reset);
 void *ht_stream(const ht_ctx *ctx); /* the hipStream_t the ctx enqueues on */
-/* ht_detect_enqueue calls served by replaying a captured hipGraph (batches of <= 16 frames: the ~10 dependent launches of a detect
+/* ht_detect_enqueue calls served by replaying a captured hipGraph (batches of <= 256 frames, option graph_max_frames: the ~10 dependent launches of a detect
  * sequence are captured once per (frames pointer, count, flags) and replayed with one hipGraphLaunch). */
 uint64_t ht_graph_launches(const ht_ctx *ctx);
 ht_status ht_synchronize(ht_ctx *ctx);

@@ -71,9 +71,24 @@ inline void hist_chunks(uint32_t npix, uint32_t max_chunks, uint32_t *chunk_px, 
     *nchunks = std::max<uint32_t>((npix + *chunk_px - 1) / *chunk_px, 1u);
 }
 
-__device__ __forceinline__ uint32_t cs_bin(uint32_t px) {  // camshift.js:63-66 (px = R | G<<8 | B<<16 | A<<24)
+// camshift.js:63-66 (px = R | G<<8 | B<<16 | A<<24): bin = (R>>4)<<8 | (G>>4)<<4 | (B>>4).  Four instructions instead of the eight of
+// the field-by-field form (the histogram pass of k_cs_track_fused spent 32 of its ~50 vector instructions per 16-byte load on its four
+// bins): with t = px & 0xf0f0f0 = r<<4 | g<<12 | b<<20 (r, g, b the 4-bit fields), t + (t << 12) puts g at bit 24 next to b at bit 20
+// (all fields of the sum are disjoint: no carries; b << 32 leaves the register), t << 24 puts r at bit 28, and the bin is bits 20-31.
+__device__ __forceinline__ uint32_t cs_bin(uint32_t px) {
+#ifdef HT_CS_BIN_FIELDS  // A/B (tools/build_alt.py): the field-by-field form
     return ((px & 0xf0u) << 4) | ((px >> 8) & 0xf0u) | ((px >> 20) & 0xfu);
+#else
+    const uint32_t t = px & 0x00f0f0f0u;
+    return ((t << 24) | (t + (t << 12))) >> 20;  // v_and, v_mul_u32_u24 0x1001, v_lshl_or_b32, v_lshrrev
+#endif
 }
+
+// A batch of PREDICATED loads (`v = ok ? p[i] : 0`) followed by cs_bin: the optimiser folds the bin's first instruction (`& 0xf0f0f0`, which maps
+// the 0 of the not-taken side to 0) into the load's own block, where it has to wait for the load on the spot — every load of the batch
+// then costs its own round trip (k_cs_hist 16.4 -> 20 us at 8 x 1080p, seen in the code object: `s_waitcnt vmcnt(0)` behind every load).
+// Laundering the loaded registers AFTER the whole batch keeps the consumers behind all of its loads.
+#define CS_BATCH_LOADED(v_) asm volatile("" : "+v"(v_))
 
 __device__ __forceinline__ int32_t toint32(double v) {  // ECMAScript ToInt32 (>>0, <<2)
     if (!(fabs(v) < 1.0e300)) return 0;                  // NaN, +-Infinity
@@ -114,6 +129,8 @@ __global__ __launch_bounds__(INIT_NT) void k_cs_init(const uint8_t *__restrict__
                 px[u] = img_ok ? img[(size_t)y * W + x] : 0u;  // getImageData outside the canvas: transparent black -> bin 0 (camshift.js:206)
             }
 #pragma unroll
+            for (int u = 0; u < 8; u++) CS_BATCH_LOADED(px[u]);
+#pragma unroll
             for (int u = 0; u < 8; u++) hist_add_wave(h, cs_bin(px[u]), 1u, in[u]);
         }
     }
@@ -151,6 +168,8 @@ __global__ __launch_bounds__(256) void k_cs_init_rows(const uint8_t *__restrict_
                 in[u] = c < rw && j < rh;
                 px[u] = (in[u] && x >= 0 && x < W && y >= 0 && y < H) ? img[(size_t)y * W + x] : 0u;  // outside the canvas: transparent black (camshift.js:206)
             }
+#pragma unroll
+            for (int u = 0; u < 4; u++) CS_BATCH_LOADED(px[u]);
 #pragma unroll
             for (int u = 0; u < 4; u++) hist_add_wave(h, cs_bin(px[u]), 1u, in[u]);
         }
@@ -206,6 +225,13 @@ __global__ __launch_bounds__(HIST_NT) void k_cs_hist(const uint8_t *__restrict__
             onv[u] = it0 + (uint32_t)u < iters && i < nquad;
             pv[u] = make_uint4(0u, 0u, 0u, 0u);
             if (onv[u]) pv[u] = img4[i];
+        }
+#pragma unroll
+        for (int u = 0; u < HT_HIST_UNROLL; u++) {
+            CS_BATCH_LOADED(pv[u].x);
+            CS_BATCH_LOADED(pv[u].y);
+            CS_BATCH_LOADED(pv[u].z);
+            CS_BATCH_LOADED(pv[u].w);
         }
 #pragma unroll
         for (int u = 0; u < HT_HIST_UNROLL; u++) {
@@ -306,7 +332,15 @@ __device__ __forceinline__ Mom window_moments(const uint32_t *__restrict__ img, 
                 for (int r = 0; r < 8; r++) {
                     const int j = min(j0 + r * nwa, hh - 1);  // clamped address, value masked below
                     if (REG) px[r] = R.bins[(y + j - R.y0) * R.rw + (x + cc - R.x0)];
-                    else px[r] = cs_bin(img[(size_t)(y + j) * W + (x + cc)]);
+                    else px[r] = img[(size_t)(y + j) * W + (x + cc)];
+                }
+                if (!REG) {
+                    // the eight loads are issued before the first bin is computed.  Left to the scheduler, one build of the 512-thread
+                    // kernel (128-VGPR cap) fetched them one at a time into ONE register — eight dependent round trips per 64 columns on
+                    // the path that streams with windows beyond the LDS region take: +9 % on the whole launch
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) px[r] = cs_bin(px[r]);
                 }
                 double val[8];
 #pragma unroll
@@ -552,16 +586,16 @@ __global__ __launch_bounds__(CS_NT) void k_cs_meanshift(const uint8_t *__restric
 // launch) and runs the mean-shift loop.  Per stream and call the only memory traffic left is the frame itself (4*W*H, then the
 // window passes from L2), the model histogram (16 KB) and the state.
 constexpr int FUSED_NT = 1024;
-constexpr int CS_REGION_CAP = 40960;  // pixels of the cached search region: 80 KB of LDS next to the 32 KB LUT and the 16 KB histogram
-// The 1024-thread form owns its CU: 128 KB of LDS and 16 wavefronts x 122 VGPRs leave no room for anything else, so the track launches
+constexpr int CS_REGION_CAP = 40960;  // pixels of the cached search region: 80 KB of LDS next to the 32 KB LUT (which the 16 KB histogram overlays)
+// The 1024-thread form owns its CU: 112 KB of LDS and 16 wavefronts x 122 VGPRs leave no room for anything else, so the track launches
 // of several contexts (and the detect kernels of their next batches) run strictly one after the other although a call is a bandwidth
 // phase (the frame streams through the histogram) followed by a latency phase (<= 10 dependent moment passes from LDS).  The
-// 512-thread form (round 5) is half of it — 8 wavefronts, <= 128 VGPRs, a 28 KB region: 77 KB of LDS — so TWO workgroups share a CU,
+// 512-thread form (round 5) is half of it — 8 wavefronts, <= 128 VGPRs, a 44 KB region: 77 KB of LDS — so TWO workgroups share a CU,
 // normally at different phases of their calls, or a workgroup shares it with another batch's detect kernels.  Its wavefronts play the
 // 16 of the large form in window_moments, so both forms return the same bits.  Chosen per launch (fused_threads below): more streams
 // than CUs, or more than one context of the device on this path.
 constexpr int FUSED_NT_SMALL = 512;
-constexpr int CS_REGION_CAP_SMALL = 14336;  // 28 KB: an 83 x 83 search window + 16 px of margin is 13 225 pixels
+constexpr int CS_REGION_CAP_SMALL = 22528;  // 44 KB: a 118 x 118 search window + 16 px of margin, or 150 x 150 without
 
 // Up to CS_SEQ_MAX successive track() calls of every stream in ONE launch (ht_camshift_track_sequence): the frame batches of the calls
 // travel as kernel arguments, a workgroup walks its stream's calls in order.  The calls of a stream depend on each other through its
@@ -594,7 +628,9 @@ __global__ __launch_bounds__(NT, 4) void k_cs_track_fused(const CsFusedArgs args
     constexpr int NWV = FUSED_NT / 64;  // wavefronts the moment passes are laid out for (window_moments), whatever NT is
     extern __shared__ __attribute__((aligned(16))) uint8_t cs_dyn[];  // [region_cap] u16 bins of the cached search region
     __shared__ double lut[4096];
-    __shared__ uint32_t h[4096];
+    // the frame's histogram overlays the upper half of the LUT it is turned into (every bin is read into registers, then a barrier,
+    // then the weights are written): 16 KB of LDS that the cached search region of the 512-thread form gets instead
+    uint32_t *const h = reinterpret_cast<uint32_t *>(lut + 2048);
     __shared__ double red[6][NWV];
     __shared__ int s_sw[4];
     (void)args_by_value;
@@ -692,21 +728,29 @@ __global__ __launch_bounds__(NT, 4) void k_cs_track_fused(const CsFusedArgs args
     CS_STAMP(stamps, 1);
     {  // getWeights, camshift.js:314-330
         const uint4 *model4 = reinterpret_cast<const uint4 *>(st.model);
+        constexpr int RND = 1024 / NT;  // 4 bins per thread and round
+        uint4 mq[RND], cq[RND];
 #pragma unroll
-        for (int i4 = threadIdx.x; i4 < 1024; i4 += NT) {  // 4 bins per thread and round (one round with 1024 threads)
-        const uint4 m = model4[i4];
-        const uint4 cv = reinterpret_cast<const uint4 *>(h)[i4];
-        if (dbg_hist) reinterpret_cast<uint4 *>(dbg_hist + (size_t)s * 4096)[i4] = cv;
-        const uint32_t chv[4] = {cv.x, cv.y, cv.z, cv.w}, mv[4] = {m.x, m.y, m.z, m.w};
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            double p = 0.0;
-            if (chv[q] != 0) {
-                p = (double)mv[q] / (double)chv[q];
-                p = p < 1.0 ? p : 1.0;
-            }
-            lut[i4 * 4 + q] = p;
+        for (int rd = 0; rd < RND; rd++) {
+            const int i4 = (int)threadIdx.x + rd * NT;
+            mq[rd] = model4[i4];
+            cq[rd] = reinterpret_cast<const uint4 *>(h)[i4];
+            if (dbg_hist) reinterpret_cast<uint4 *>(dbg_hist + (size_t)s * 4096)[i4] = cq[rd];
         }
+        __syncthreads();  // every bin of h is in a register: the weights may overwrite it
+#pragma unroll
+        for (int rd = 0; rd < RND; rd++) {
+            const int i4 = (int)threadIdx.x + rd * NT;
+            const uint32_t chv[4] = {cq[rd].x, cq[rd].y, cq[rd].z, cq[rd].w}, mv[4] = {mq[rd].x, mq[rd].y, mq[rd].z, mq[rd].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                double p = 0.0;
+                if (chv[q] != 0) {
+                    p = (double)mv[q] / (double)chv[q];
+                    p = p < 1.0 ? p : 1.0;
+                }
+                lut[i4 * 4 + q] = p;
+            }
         }
     }
     CS_STAMP(stamps, 2);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/gpu_refresh_c3.sh — after a change that only touches the camshift fused kernel: parity suite, the driver's bench line, the
+# tools/gpu_refresh_c3.sh — after a change that only touches the camshift kernels: parity suite, the driver's bench line, the
 # flag-less line, C3 at 2 / 3 / 4 steps in flight, rocprofv3 kernel stats + PMC passes of C3 (both forms of k_cs_track_fused)
 set -u
 OUT=gpurun_out; mkdir -p $OUT
@@ -17,7 +17,10 @@ import sys, json
 j = json.loads(sys.stdin.readline())
 print('c3 steps in flight $d:', j['value'], 'frames/s', j['ms_per_step'], 'ms/step', j.get('parity_exact'))" | tee -a $OUT/c3_depth.txt
 done
+rm -f $OUT/cs_step.txt; for f in 8 1; do timeout 200 python tools/gpu_cs_step.py $f 2>/dev/null | tail -1 >> $OUT/cs_step.txt; done; cat $OUT/cs_step.txt
 cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_c5 -o c5 -- python $GRAFT_REPO_ROOT/bench.py --workload c5 --feeds 8 --steps 60 --warmup 2 --cpu-seconds 0 --prewarm 0 --pipeline 1 --no-sub > $GRAFT_REPO_ROOT/$OUT/prof_c5.log 2>&1
+echo "rocprofv3 stats c5 exit $?"
 for form in 1024 512; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof_c3_$form -o c3 -- python $GRAFT_REPO_ROOT/bench.py --workload c3 --steps 2 --warmup 2 --cpu-seconds 0 --prewarm 0 --pipeline 1 --no-sub --options cs_fused_nt=$form > $GRAFT_REPO_ROOT/$OUT/prof_c3_$form.log 2>&1
   echo "rocprofv3 stats c3 form $form exit $?"

@@ -82,3 +82,25 @@ def test_camshift_case(case):
             assert math.isnan(to["angle"])
         else:
             assert abs(to["angle"] - call["angle"]) <= 1e-12
+
+
+def test_four_instruction_histogram_bin_equals_the_reference_formula_exhaustively():
+    """ht_camshift.hip's cs_bin computes camshift.Histogram's bin (camshift.js:63-66: 256 * (R >> 4) + 16 * (G >> 4) + (B >> 4)) from the
+    packed pixel R | G << 8 | B << 16 | A << 24 as ((t << 24) | (t + (t << 12))) >> 20 with t = px & 0xf0f0f0, in 32-bit arithmetic; the
+    code object multiplies by 0x1001 with v_mul_u32_u24 (t is a 24-bit value).  Every RGB value, alpha 0 / 0x5a / 0xff, against the
+    reference formula — and the source must still hold the expression this test restates."""
+    import os
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "headtrackr_amd", "csrc", "ht_camshift.hip")).read()
+    body = re.search(r"uint32_t cs_bin\(uint32_t px\) \{(.*?)\n\}", src, re.S).group(1)
+    assert "px & 0x00f0f0f0u" in body and "((t << 24) | (t + (t << 12))) >> 20" in body
+    rgb = np.arange(1 << 24, dtype=np.uint32)
+    want = 256 * ((rgb & 0xFF) >> 4) + 16 * (((rgb >> 8) & 0xFF) >> 4) + (((rgb >> 16) & 0xFF) >> 4)
+    for alpha in (0x00, 0x5A, 0xFF):
+        px = rgb | np.uint32(alpha << 24)
+        t = px & np.uint32(0x00F0F0F0)
+        got = ((t << np.uint32(24)) | (t + (t << np.uint32(12)))) >> np.uint32(20)  # uint32: wraps like the device registers
+        assert got.dtype == np.uint32 and np.array_equal(got, want), hex(alpha)
+        mul = (t.astype(np.uint64) * 0x1001 & 0xFFFFFFFF).astype(np.uint32)  # the v_mul_u32_u24 form of t + (t << 12)
+        assert np.array_equal(mul, t + (t << np.uint32(12)))

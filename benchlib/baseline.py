@@ -29,6 +29,39 @@ def _node_ref(raw, args, seconds):
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
+def port_all_cores(frames, blob, seconds):
+    """SURVEY.md §8(d)'s optional second line: the C port on every host core this process may use — one thread per core
+    (ctypes drops the GIL inside ho_detect_raw, the port keeps no global state), frames dealt out round-robin, each
+    thread stops taking frames once the budget has run out.  The reference itself is single-threaded JS; this is what
+    its arithmetic would deliver if somebody parallelised it over frames."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import ht_oracle as ho
+
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    nf = len(frames)
+    t0 = time.perf_counter()
+
+    def worker(tid):
+        done, i = 0, tid
+        while done < 1 or time.perf_counter() - t0 < seconds:
+            ho.detect_raw(frames[i % nf], blob)
+            done, i = done + 1, i + cores
+        return done
+
+    try:
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            done = sum(ex.map(worker, range(cores)))
+        dt = time.perf_counter() - t0
+        return dict(value=round(done / dt, 2), unit="frames/s", cores=cores, kind="port",
+                    sample=f"{done} detect calls on the first {min(nf, done)} frames in {dt:.1f} s, one thread per core")
+    except Exception as e:  # a baseline leg never costs the line
+        return dict(error=f"{type(e).__name__}: {e}")
+
+
 def cpu_detect_baseline(frames, W, H, blob, seconds):
     """(reference-JS record or the port standing in, port record) for ccv.grayscale + ccv.detect_objects(..., 5, 1)"""
     from oracle import ht_oracle as ho
@@ -44,6 +77,7 @@ def cpu_detect_baseline(frames, W, H, blob, seconds):
     port = dict(value=round(done / cdt, 3), unit="frames/s", cores=1, kind="port", host_cpus=os.cpu_count(),
                 sample=f"first {done} of the {nf} {W}x{H} frames of this workload, oracle/ht_oracle.c detect "
                        "(gray+pyramid+scan), 1 thread")
+    port["all_cores"] = port_all_cores(frames, blob, seconds / 3)
     try:
         ns = min(nf, 64)
         j = _node_ref(frames[:ns], [ns, W, H, seconds], seconds)

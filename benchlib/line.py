@@ -67,6 +67,10 @@ def compose(metric, prim, sub, world, extra=None):
         line["cpu_baseline_note"] = "N = 1 only"
     scal = {
         "vs_cpu": prim.get("vs_cpu"),
+        # the C port of the same arithmetic, one thread / one thread per host core (SURVEY.md §8(d)'s optional second line)
+        "cpu_port_1core_value": get(prim, "cpu_baseline_port", "value"),
+        "cpu_port_all_cores_value": get(prim, "cpu_baseline_port", "all_cores", "value"),
+        "cpu_port_all_cores": get(prim, "cpu_baseline_port", "all_cores", "cores"),
         "path_hbm_frac": prim.get("path_hbm_frac"), "wall_hbm_frac": prim.get("wall_hbm_frac"),
         "valu_issue_frac": get(prim, "valu_issue", "frac_wall"),
         "device_ms_per_step": prim.get("device_ms_per_step"),
@@ -88,6 +92,7 @@ def compose(metric, prim, sub, world, extra=None):
             "depth1_ms_per_step_720p": get(c4, "depth1", "ms_per_step"),
             "pcie_inclusive_value_720p": get(c4, "pcie_inclusive", "value"),
             "cpu_baseline_720p": get(c4, "cpu_baseline", "value"),
+            "cpu_port_all_cores_value_720p": get(c4, "cpu_baseline_port", "all_cores", "value"),
             "north_star_720p_vs_reference_js": c4.get("vs_cpu"),  # target: >= 30x on 1280x720 detect at 1 GPU
             "allgather_verified_720p": c4.get("allgather_verified"),
         })

@@ -27,7 +27,10 @@ def _detect(value, ms):
             "ms_per_step_max": ms * 1.02, "scaling": "weak",
             "config": {"workload": "C2: 256 x 320x240 RGBA frames per GPU, " + "w" * 200, "frames_per_gpu": 256, "frames_total": 256,
                        "batches_in_flight": 3, "width": 320, "height": 240, "unique_frames": 256, "frame_mix": "m" * 60, "parallelism": "p" * 200},
-            "roofline": _roof("resample"), "cpu_baseline": _cpu(), "vs_cpu": 27400.1, "path_hbm_frac": 0.11712, "wall_hbm_frac": 0.16512,
+            "roofline": _roof("resample"), "cpu_baseline": _cpu(),
+            "cpu_baseline_port": dict(value=321.5, unit="frames/s", cores=1, kind="port", sample="p" * 200,
+                                      all_cores=dict(value=41234.5, unit="frames/s", cores=256, kind="port", sample="q" * 200)),
+            "vs_cpu": 27400.1, "path_hbm_frac": 0.11712, "wall_hbm_frac": 0.16512,
             "valu_issue": dict(frac_wall=0.6712, frac_device=0.4812), "device_ms_per_step": 0.31812, "rank_ms_per_step_min": ms, "rank_ms_per_step_max": ms,
             "depth1": dict(ms_per_step=0.3412, value=750000.1), "pcie_inclusive": dict(value=181234.5, h2d_gbs=55.61), "allgather_verified": True,
             "kernel_ms_per_step": {k: 0.1 for k in ("gray", "resample", "scan_tiles", "scan_deep")}, "kernel_rooflines": {"gray": {"x": 1}},
@@ -64,6 +67,8 @@ def test_full_size_line_is_a_compact_headline(tmp_path, monkeypatch):
     assert got["cpu_baseline"]["kind"] == "reference" and len(got["cpu_baseline"]["sample"]) <= bl.SAMPLE_CAP
     assert got["value_720p"] == 115123.4 and got["north_star_720p_vs_reference_js"] == 27400.1 and got["c3_value"] == 6881234.5
     assert got["c5_value"] == 120034.5 and got["valu_issue_frac"] == 0.6712 and got["depth1_ms_per_step"] == 0.3412
+    assert got["cpu_port_1core_value"] == 321.5 and got["cpu_port_all_cores_value"] == 41234.5 and got["cpu_port_all_cores"] == 256
+    assert got["cpu_port_all_cores_value_720p"] == 41234.5
     assert got["parity_exact"].startswith("c3 480/480; c5 232/232 + best faces 16/16")
     assert "sub" not in got and got["sub_file"] == "bench_sub.json"
     side = json.load(open(tmp_path / "bench_sub.json"))

@@ -32,6 +32,23 @@ def test_header_symbols_all_exported(built_lib):
     assert sorted(native.SYMBOLS) == syms, "native.SYMBOLS is out of sync with include/headtrackr_hip.h"
 
 
+def test_integration_doc_lists_every_export_and_addon_function():
+    """INTEGRATION.md §6 is the binding table a maintainer reads: every symbol of the header has a row, and every addon function the
+    table names exists in csrc/ht_napi.cc's export list."""
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("## 6. Every export"):]
+    rows = dict(re.findall(r"^\| `(ht_[a-z0-9_]+)` \|.*\| ([^|]*) \|$", table, flags=re.M))
+    assert sorted(rows) == declared_symbols()
+    napi = open(os.path.join(ROOT, "headtrackr_amd", "csrc", "ht_napi.cc")).read()
+    exported = set(re.findall(r'\{"(\w+)",\s*\w+\}', napi))
+    assert len(exported) >= 35
+    for sym, cell in rows.items():
+        if cell.startswith("—") or cell.startswith("checked in") or cell.startswith("every thrown"):
+            continue  # reached through ctypes only / not a function of its own
+        for fn in re.findall(r"`(\w+)", cell):
+            assert fn in exported, (sym, fn)
+
+
 def test_abi_version_and_struct_sizes(built_lib):
     assert built_lib.ht_abi_version() == 2
     assert C.sizeof(native.Config) == 40 and native.Config.options.offset == 32  # ABI 1 callers pass struct_size 32 (no options)

@@ -119,6 +119,22 @@ def mainjs_cases():
             dict(name="mainjs_debug_noangles", kind="mainjs", w=W, h=H, debug=True, params=dict(calcAngles=False, smoothing=False), gens=gens[:22])]
 
 
+def large_cases():
+    """The largest frame size of BASELINE.json (configs[4]: 1920x1080 feeds): pins the ORACLE to the reference there.  A file of its own,
+    read only by the CPU test of the oracle (tests/test_oracle_golden.py) — the GPU suite compares the HIP path with the oracle at this
+    size (pyramid planes, the C5 loop), so reference -> oracle -> GPU holds at 1080p as well."""
+    W, H = 1920, 1080
+    cs = []
+    ops = ["gray", "pyramid", "raw", "grouped", "whitebalance"]
+    cs.append(dict(name="faces_1920x1080", kind="detect", w=W, h=H, ops=ops,
+                   gen=dict(family="face", faces=[[700, 300, 400], [1500, 120, 90], [200, 700, 260]])))
+    cs.append(dict(name="smooth_1920x1080", kind="detect", w=W, h=H, ops=ops, gen=dict(family="smooth", seed=1080)))
+    # C5's camshift shape: a ~360 x 360 search window on a 1080p frame, target walking 4 px / frame
+    gens = [dict(family="blob", cx=960 + 4 * k, cy=540 - 3 * k, a=180, b=110, rot=[12, 5, 13], color=[210, 140, 40], seed=31 + k) for k in range(5)]
+    cs.append(dict(name="cs_1080p", kind="camshift", w=W, h=H, calcAngles=True, rect=[780, 400, 360, 280], gens=gens))
+    return cs
+
+
 def run(cases, out_name):
     with tempfile.TemporaryDirectory() as td:
         cache = {}
@@ -161,3 +177,4 @@ if __name__ == "__main__":
     run(facetrackr_cases(), "facetrackr.json")
     run(post_cases(), "post.json")
     run(mainjs_cases(), "debug.json")
+    run(large_cases(), "large.json")

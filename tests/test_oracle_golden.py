@@ -14,6 +14,7 @@ from oracle import ht_oracle as ho
 
 DETECT = load_golden("detect.json")
 CAMSHIFT = load_golden("camshift.json")
+LARGE = load_golden("large.json")
 
 
 def creation_order(nlevels, next_):
@@ -33,6 +34,10 @@ def test_v8_scale_constants():
 
 @pytest.mark.parametrize("case", DETECT["cases"], ids=lambda c: c["name"])
 def test_detect_case(case, cascade):
+    check_detect_case(case, cascade)
+
+
+def check_detect_case(case, cascade):
     w, h = case["w"], case["h"]
     interval = 5 if "interval3" not in case["name"] else 3
     frame = synth.make(case["gen"], w, h)
@@ -69,6 +74,21 @@ def test_detect_case(case, cascade):
 
 @pytest.mark.parametrize("case", CAMSHIFT["cases"], ids=lambda c: c["name"])
 def test_camshift_case(case):
+    check_camshift_case(case)
+
+
+@pytest.mark.parametrize("case", LARGE["cases"], ids=lambda c: c["name"])
+def test_largest_frame_size_1080p(case, cascade):
+    """tests/golden/large.json: the reference itself at 1920x1080 (the frame size of BASELINE.json configs[4]) — two detect cases
+    (all 119 pyramid planes by CRC, raw hits incl. confidence, grouped faces) and a camshift sequence with a ~360 x 360 search window.
+    The GPU suite compares the HIP path with the oracle at this size; this pins the oracle there."""
+    if case["kind"] == "detect":
+        check_detect_case(case, cascade)
+    else:
+        check_camshift_case(case)
+
+
+def check_camshift_case(case):
     w, h = case["w"], case["h"]
     frames = [synth.make(g, w, h) for g in case["gen"]]
     tr = ho.Camshift(calc_angles=case["calcAngles"])

@@ -5,7 +5,8 @@ const path = require('path');
 const fs = require('fs');
 const root = path.join(__dirname, '..', '..');
 const ht = require(path.join(root, 'headtrackr_amd', 'js', 'headtrackr.js'));
-const golden = JSON.parse(fs.readFileSync(path.join(root, 'tests', 'golden', 'detect.json'), 'utf8'));
+/* optional arguments: other files of the same shapes (tools/cpu_soak_reference.py passes the reference's output on random cases) */
+const golden = JSON.parse(fs.readFileSync(process.argv[2] || path.join(root, 'tests', 'golden', 'detect.json'), 'utf8'));
 const out = { ok: true, errors: [] };
 function check(cond, msg) { if (!cond) { out.ok = false; out.errors.push(msg); } }
 
@@ -31,7 +32,7 @@ golden.cases.forEach(function (cs) {
   }
 });
 /* host post-processing (SURVEY.md §8f) against the reference-JS vectors: Smoother and headposition are pure math */
-const post = JSON.parse(fs.readFileSync(path.join(root, 'tests', 'golden', 'post.json'), 'utf8'));
+const post = JSON.parse(fs.readFileSync(process.argv[3] || path.join(root, 'tests', 'golden', 'post.json'), 'utf8'));
 post.cases.forEach(function (cs) {
   if (cs.kind === 'smoother') {
     const sm = new ht.Smoother(cs.alpha, cs.interval);

@@ -6,7 +6,9 @@ path with the oracle on thousands of random geometries.  This closes the remaini
 families, intervals, min_neighbors and tracker set-ups are run through /root/reference/headtrackr.js (oracle/ref_harness.js on
 oracle/canvas_shim.js, exactly as tests/golden/make_golden.py does) and through the oracle, and compared with the SAME checks as
 tests/test_oracle_golden.py: input CRC, whitebalance, gray bytes, every pyramid plane (size + CRC), raw rects incl. the binary64
-confidence, grouped rects; camshift search window / x / y / width / height exact and the angle to 1e-12.
+confidence, grouped rects; camshift search window / x / y / width / height exact and the angle to 1e-12.  On the same reference
+output the PRODUCT's host-side code is checked too (no GPU needed): ht_group_rects of libheadtrackr_hip.so, and through
+tests/js/facade_cpu.js the JS facade's grouping, Smoother and headposition.Tracker on random sequences.
 Needs /root/reference and node (this container, not the GPU box).  Exit 1 on the first mismatch, with the case's generator spec."""
 import importlib.util
 import json
@@ -84,14 +86,82 @@ def camshift_case(i):
     return dict(name=f"soakcs{i}", kind="camshift", w=w, h=h, calcAngles=bool(rng.random() < 0.7), rect=rect, gens=gens)
 
 
+def post_cases(i):
+    """headtrackr.Smoother (smoother.js:13-88) and headposition.Tracker (headposition.js:35-201): pure host arithmetic of SURVEY §8(f3),
+    restated in headtrackr_amd/js/tracker.js"""
+    n = int(rng.integers(3, 30))
+    pos = [[float(v) for v in rng.uniform(-50, 700, 5)] for _ in range(n)]
+    if rng.random() < 0.5:
+        pos = [[int(v) for v in p] for p in pos]
+    sm = dict(name=f"soaksm{i}", kind="smoother", alpha=float(rng.choice([0.35, 0.5, 0.1, 0.9, float(rng.uniform(0.01, 0.99))])),
+              interval=int(rng.integers(1, 60)), positions=pos)
+    if rng.random() < 0.3:
+        sm["init_at"] = int(rng.integers(0, n))
+    camw, camh = int(rng.integers(64, 1921)), int(rng.integers(48, 1081))
+    faces = [[float(rng.uniform(-20, camw + 20)), float(rng.uniform(-20, camh + 20)), float(rng.uniform(8, camw / 2)), float(rng.uniform(8, camh / 2))]
+             for _ in range(int(rng.integers(2, 30)))]
+    params = {}
+    if rng.random() < 0.5:
+        params["fov"] = float(rng.uniform(20, 90))
+    if rng.random() < 0.5:
+        params["edgecorrection"] = bool(rng.random() < 0.5)
+    if rng.random() < 0.5:
+        params["distance_from_camera_to_screen"] = float(rng.uniform(0, 30))
+    if rng.random() < 0.3:
+        params["distance_to_screen"] = float(rng.uniform(30, 120))
+    return [sm, dict(name=f"soakhp{i}", kind="headposition", camw=camw, camh=camh, params=params, faces=faces)]
+
+
+def lib_group(rects, min_neighbors):
+    """the product's own host grouping (ht_group_rects, csrc/ht_hostpost.h: what the Python / C hosts and ht_detect_collect_best use)"""
+    import ctypes as C
+
+    from headtrackr_amd import native
+
+    out = np.zeros(max(1, len(rects)), dtype=native.RECT_DTYPE)
+    n = C.c_uint32(0)
+    assert native.lib().ht_group_rects(rects.ctypes.data, len(rects), min_neighbors, out.ctypes.data, C.byref(n)) == 0
+    return out[: n.value]
+
+
+def check_product_host(td, res):
+    """The PRODUCT's host code against the reference's output of the same random cases (no GPU involved): ht_group_rects in C, and —
+    through tests/js/facade_cpu.js — the JS facade's grouping (ccv._group), Smoother and headposition.Tracker."""
+    import subprocess
+
+    from headtrackr_amd import native
+
+    det = [c for c in res["cases"] if c["kind"] == "detect"]
+    for c in det:
+        raw = np.zeros(len(c["raw"]), dtype=native.RECT_DTYPE)
+        for k in ("x", "y", "width", "height", "confidence"):
+            raw[k] = [r[k] for r in c["raw"]]
+        raw["neighbors"] = 1
+        got = lib_group(raw, c["min_neighbors"])
+        assert len(got) == len(c["grouped"]), (c["name"], "ht_group_rects count")
+        for g, w in zip(got, c["grouped"]):
+            for k in ("x", "y", "width", "height", "confidence", "neighbors"):
+                assert g[k] == w[k], (c["name"], "ht_group_rects", k, g, w)
+    with open(os.path.join(td, "soak_detect.json"), "w") as f:
+        json.dump(dict(cases=det), f)
+    with open(os.path.join(td, "soak_post.json"), "w") as f:
+        json.dump(dict(cases=[c for c in res["cases"] if c["kind"] in ("smoother", "headposition")]), f)
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "facade_cpu.js"), os.path.join(td, "soak_detect.json"),
+                        os.path.join(td, "soak_post.json")], capture_output=True, text=True, timeout=300)
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["ok"], ("JS facade vs reference", j["errors"][:5])
+
+
 def main():
     t0 = time.time()
-    tot = dict(detect=0, planes=0, raw=0, grouped=0, camshift=0, calls=0, sizes=set())
+    tot = dict(detect=0, planes=0, raw=0, grouped=0, camshift=0, calls=0, post=0, sizes=set())
     batch_no = 0
     with tempfile.TemporaryDirectory() as td:
         mg.OUT = td
         while time.time() - t0 < BUDGET:
             cases = [detect_case(batch_no * 100 + i) for i in range(16)] + [camshift_case(batch_no * 100 + i) for i in range(8)]
+            for i in range(4):
+                cases += post_cases(batch_no * 100 + i)
             sys.stdout.flush()
             sys.stderr.flush()
             keep, null = (os.dup(1), os.dup(2)), os.open(os.devnull, os.O_WRONLY)
@@ -107,8 +177,16 @@ def main():
                     os.close(fd)
             with open(os.path.join(td, "soak.json")) as f:
                 res = json.load(f)
+            try:
+                check_product_host(td, res)
+                tot["post"] += 8
+            except AssertionError as e:
+                print("MISMATCH product host code vs reference, batch", batch_no, "seed", SEED, "\n", e)
+                return 1
             for spec, got in zip(cases, res["cases"]):
                 try:
+                    if got["kind"] in ("smoother", "headposition"):
+                        continue
                     if got["kind"] == "detect":
                         tg.check_detect_case(got, cascade)
                         tot["detect"] += 1
@@ -126,7 +204,9 @@ def main():
             batch_no += 1
     print(f"oracle vs reference JS soak, seed {SEED}, {time.time() - t0:.0f} s: {tot['detect']} detect cases + {tot['camshift']} camshift set-ups over "
           f"{len(tot['sizes'])} geometries; {tot['planes']} pyramid planes (size + CRC), {tot['raw']} raw rects incl. confidence bits, "
-          f"{tot['grouped']} grouped faces, {tot['calls']} track() calls (window / x / y / width / height exact, angle to 1e-12): all identical")
+          f"{tot['grouped']} grouped faces, {tot['calls']} track() calls (window / x / y / width / height exact, angle to 1e-12): all identical.  "
+          f"Product host code on the same reference output: ht_group_rects (C) and the JS facade's ccv._group on every raw list, "
+          f"{tot['post']} random Smoother / headposition sequences through headtrackr_amd/js: all identical")
     return 0
 
 

@@ -230,6 +230,7 @@ function groupSeq(seq, min_neighbors) {
 }
 
 headtrackr.ccv._group = groupSeq; /* exposed for tests */
+headtrackr.ccv._hitsToSeq = hitsToSeq; /* likewise */
 
 /* ccv.js:109: `canvas` is expected to be gray already (byte 0 of each pixel is what the detector reads) */
 headtrackr.ccv.detect_objects = function (canvas, cascade, interval, min_neighbors) {

@@ -23,6 +23,14 @@ const mod = require('module');
 golden.cases.forEach(function (cs) {
   const seq = cs.raw.map(function (r) { return { x: r.x, y: r.y, width: r.width, height: r.height, neighbor: 1, confidence: r.confidence }; });
   /* reuse the facade's private grouping through detect_objects' tail: exposed for tests as ccv._group */
+  if (cs.hits) { /* raw hits in index form (the shape the addon returns; here from the oracle): the facade's own seq construction */
+    const built = ht.ccv._hitsToSeq(cs.hits, 0, cs.hits.x.length, ht.cascade, cs.interval === undefined ? 5 : cs.interval);
+    check(built.length === cs.raw.length, cs.name + ': seq length ' + built.length + ' != ' + cs.raw.length);
+    for (let i = 0; i < Math.min(built.length, cs.raw.length); i++) {
+      ['x', 'y', 'width', 'height', 'confidence'].forEach(function (k) { check(built[i][k] === cs.raw[i][k], cs.name + ': seq[' + i + '].' + k); });
+    }
+    out.seq_checked = (out.seq_checked || 0) + built.length;
+  }
   const got = ht.ccv._group(seq, cs.min_neighbors);
   check(got.length === cs.grouped.length, cs.name + ': grouped count ' + got.length + ' != ' + cs.grouped.length);
   for (let i = 0; i < Math.min(got.length, cs.grouped.length); i++) {

@@ -142,6 +142,14 @@ def check_product_host(td, res):
         for g, w in zip(got, c["grouped"]):
             for k in ("x", "y", "width", "height", "confidence", "neighbors"):
                 assert g[k] == w[k], (c["name"], "ht_group_rects", k, g, w)
+    from headtrackr_amd import synth
+    from oracle import ht_oracle as ho
+
+    for c in det:  # raw hits in the addon's index form (from the oracle: the checker) for the facade's own seq construction
+        iv = 3 if "interval3" in c["name"] else 5
+        hits = ho.detect_raw(synth.make(c["gen"], c["w"], c["h"]), cascade.blob, interval=iv)
+        c["interval"] = iv
+        c["hits"] = {k: [float(v) if k == "sum" else int(v) for v in hits[k]] for k in ("scale", "q", "x", "y", "sum")}
     with open(os.path.join(td, "soak_detect.json"), "w") as f:
         json.dump(dict(cases=det), f)
     with open(os.path.join(td, "soak_post.json"), "w") as f:
@@ -205,7 +213,7 @@ def main():
     print(f"oracle vs reference JS soak, seed {SEED}, {time.time() - t0:.0f} s: {tot['detect']} detect cases + {tot['camshift']} camshift set-ups over "
           f"{len(tot['sizes'])} geometries; {tot['planes']} pyramid planes (size + CRC), {tot['raw']} raw rects incl. confidence bits, "
           f"{tot['grouped']} grouped faces, {tot['calls']} track() calls (window / x / y / width / height exact, angle to 1e-12): all identical.  "
-          f"Product host code on the same reference output: ht_group_rects (C) and the JS facade's ccv._group on every raw list, "
+          f"Product host code on the same reference output: ht_group_rects (C) and the JS facade's seq construction + ccv._group on every raw list, "
           f"{tot['post']} random Smoother / headposition sequences through headtrackr_amd/js: all identical")
     return 0
 

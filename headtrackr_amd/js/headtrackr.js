@@ -471,6 +471,9 @@ headtrackr.getWhitebalance = function (canvas) { /* whitebalance.js:5-30 */
   const img = canvas.getContext('2d').getImageData(0, 0, canvas.width, canvas.height);
   if (!(img.width > 0 && img.height > 0)) return NaN; /* 0/0 in the reference */
   const c = contextFor(headtrackr.cascade, 5);
+  /* announce the size like every other entry point: a frame of another size would make the addon re-build the geometry on its own, with
+   * level sizes from libm instead of V8's, behind the back of the cache in `c` (found by tests/js/parity_cpu.js) */
+  ensureGeometry(c, img.width, img.height, 1, headtrackr.cascade, 5);
   c.boundImg = null;
   return addon().whitebalance(c.handle, img.data, 1, img.width, img.height)[0];
 };

@@ -30,10 +30,8 @@ def test_facade_exports_and_host_grouping():
     assert out["abi"] == 2
 
 
-@pytest.mark.gpu
-@pytest.mark.skipif(NODE is None, reason="node is not installed")
-def test_js_host_parity_on_gpu(tmp_path):
-    _build()
+def _parity_job(tmp_path):
+    """the golden vectors of the reference JS as a job for tests/js/parity_gpu.js (frames written as raw RGBA files)"""
     det, cam, ft = load_golden("detect.json"), load_golden("camshift.json"), load_golden("facetrackr.json")
     cache = {}
 
@@ -65,6 +63,52 @@ def test_js_host_parity_on_gpu(tmp_path):
     for c in dbg["cases"]:
         job["mainjs"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=[ffile(x, c["w"], c["h"]) for x in c["gen"]],
                                   golden={k: c[k] for k in ("params", "calls", "fov")}))
+    return job
+
+
+def _build_oracle_addon():
+    """tests/js/oracle_addon.node: the CPU oracle as a Node addon (test infrastructure, compiled with the oracle's own flags)"""
+    src, out = os.path.join(ROOT, "tests", "js", "oracle_addon.c"), os.path.join(ROOT, "tests", "js", "oracle_addon.node")
+    dep = os.path.join(ROOT, "oracle", "ht_oracle.c")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(dep)):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-std=c11", "-D_GNU_SOURCE",
+                               "-I/usr/include/node", src, "-o", out, "-lm"])
+    return out
+
+
+@pytest.mark.skipif(NODE is None or not os.path.exists("/usr/include/node/node_api.h"), reason="node / node_api.h not installed")
+def test_js_facade_host_logic_on_the_cpu_mock(tmp_path):
+    """The UNCHANGED JavaScript facade (headtrackr.js + tracker.js) against the reference-JS golden vectors without a GPU: the product
+    addon is replaced by tests/js/mock_addon.js (its single-frame entry points on the CPU oracle), everything above the addon interface
+    is the product's code — seq construction, grouping, getWhitebalance, camshift.Tracker with its debug getters, the facetrackr WB -> VJ
+    -> CS state machine with its events, the headtrackr.Tracker loop (status events, Smoother, headposition) and the main.js debug overlay
+    (stroke calls + canvas pixels), at every golden frame size."""
+    _build_oracle_addon()
+    job = _parity_job(tmp_path)
+    job["cpu_mock"] = True
+    jf = tmp_path / "job.json"
+    jf.write_text(json.dumps(job))
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "parity_cpu.js"), str(jf)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"], out["errors"]
+    assert out["checked"] > 1700
+    exact, total = (int(v) for v in out["cs_parity"].split("/"))
+    assert total > 0 and exact == total
+    calls = out["addon_calls"]  # the facade really went through the addon interface
+    for k in ("createContext", "setGeometry", "upload", "grayscale", "detect", "detectEnqueue", "detectCollect", "whitebalance",
+              "whitebalanceBound", "camshiftReserve", "camshiftInitBound", "camshiftTrackBound"):
+        assert calls.get(k, 0) > 0, (k, calls)
+    # every frame size was announced through setGeometry (V8-computed level sizes, headtrackr.js levelDims): the addon never had to
+    # re-build a geometry on its own (this run found getWhitebalance skipping that step)
+    assert calls.get("implicitGeometry", 0) == 0, calls
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_js_host_parity_on_gpu(tmp_path):
+    _build()
+    job = _parity_job(tmp_path)
     jf = tmp_path / "job.json"
     jf.write_text(json.dumps(job))
     # (with one visible GPU the sharded call has one rank and skips RCCL; tests/test_gpu_shapes.py::test_allgather_best_faces_over_rccl

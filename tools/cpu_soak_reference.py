@@ -37,6 +37,8 @@ rng = np.random.default_rng(SEED)
 mg = load(os.path.join(ROOT, "tests", "golden", "make_golden.py"), "make_golden")
 tg = load(os.path.join(ROOT, "tests", "test_oracle_golden.py"), "test_oracle_golden")
 cascade = load_cascade()
+# the JS facade's state machines need the oracle as a Node addon (tests/test_js_host.py builds it: tests/js/oracle_addon.node)
+MOCK = os.path.exists(os.path.join(ROOT, "tests", "js", "oracle_addon.node"))
 
 
 def rand_gen(w, h):
@@ -112,6 +114,90 @@ def post_cases(i):
     return [sm, dict(name=f"soakhp{i}", kind="headposition", camw=camw, camh=camh, params=params, faces=faces)]
 
 
+def face_walk(w, h, n, vanish_at=None):
+    """gens of n frames: one vote-image face walking <= 3 px per frame; from vanish_at on a flat gray frame (the track is lost)"""
+    s0 = int(rng.integers(40, max(41, min(w, h) - 16)))
+    x, y = int(rng.integers(0, w - s0 + 1)), int(rng.integers(0, h - s0 + 1))
+    gens = []
+    for k in range(n):
+        if vanish_at is not None and k >= vanish_at:
+            gens.append(dict(family="face", faces=[], gray=250))
+        else:
+            gens.append(dict(family="face", faces=[[x, y, s0]]))
+        x = int(np.clip(x + rng.integers(-3, 4), 0, w - s0))
+        y = int(np.clip(y + rng.integers(-3, 4), 0, h - s0))
+    return gens
+
+
+def facade_cases(i):
+    """the reference's stateful objects on random sequences: facetrackr.Tracker (facetrackr.js:37-228: WB -> VJ -> CS), the per-frame body of
+    headtrackr.Tracker composed from them (main.js:168-305: lost track, Smoother, headposition) and the reference's own main.js loop with a
+    debug canvas (main.js:199-219).  Compared through tests/js/parity_cpu.js: the product's facade on the oracle-backed mock addon."""
+    out = []
+    w, h = [(160, 120), (200, 150), (320, 240), (int(rng.integers(96, 400)), int(rng.integers(72, 300)))][int(rng.integers(0, 4))]
+    wb = bool(rng.random() < 0.4)
+    n = int(rng.integers(18, 23)) if wb else int(rng.integers(5, 12))
+    fam = rng.random()
+    if fam < 0.15:
+        gens = [dict(family="noise", seed=int(rng.integers(1, 1 << 20))) for _ in range(n)]  # nothing to find
+    else:
+        gens = face_walk(w, h, n, vanish_at=(int(rng.integers(n - 4, n)) if fam < 0.4 and n > 6 else None))
+    out.append(dict(name=f"soakft{i}", kind="facetrackr", w=w, h=h, gens=gens,
+                    params=dict(whitebalancing=wb, calcAngles=bool(rng.random() < 0.5))))
+    n = int(rng.integers(8, 20))
+    gens = face_walk(w, h, n, vanish_at=(int(rng.integers(4, n - 2)) if rng.random() < 0.5 else None))
+    if rng.random() < 0.5:
+        gens += face_walk(w, h, int(rng.integers(3, 8)))  # a face again: re-detection
+    out.append(dict(name=f"soakpl{i}", kind="pipeline", w=w, h=h, whitebalancing=False, gens=gens,
+                    params=dict(calcAngles=bool(rng.random() < 0.5))))
+    if i % 4 == 0:  # the main.js loop starts with its whitebalance phase: 16 identical frames first
+        first = face_walk(320, 240, 1)
+        gens = first * 16 + face_walk(320, 240, int(rng.integers(4, 10)), vanish_at=(3 if rng.random() < 0.5 else None))
+        out.append(dict(name=f"soakmj{i}", kind="mainjs", w=320, h=240, debug=True, gens=gens,
+                        params=dict(calcAngles=bool(rng.random() < 0.5), smoothing=bool(rng.random() < 0.7))))
+    return out
+
+
+def check_facade(td, specs, res):
+    """facetrackr / pipeline / mainjs results of the reference -> a job for tests/js/parity_cpu.js (the unchanged product facade on the mock addon)"""
+    import subprocess
+
+    from headtrackr_amd import synth
+
+    fdir = os.path.join(td, "frames")
+    os.makedirs(fdir, exist_ok=True)
+    cache = {}
+
+    def ffile(gen, w, h):
+        key = json.dumps([gen, w, h], sort_keys=True)
+        if key not in cache:
+            cache[key] = os.path.join("frames", f"f{len(cache)}.raw")
+            synth.make(gen, w, h).tofile(os.path.join(td, cache[key]))
+        return cache[key]
+
+    job = {"detect": [], "camshift": [], "facetrackr": [], "pipeline": [], "mainjs": [], "cpu_mock": True}
+    for spec, c in zip(specs, res["cases"]):
+        fr = None if c["kind"] not in ("facetrackr", "pipeline", "mainjs") else [ffile(g, c["w"], c["h"]) for g in spec["gens"]]
+        if c["kind"] == "facetrackr":
+            job["facetrackr"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=fr, golden={k: c[k] for k in ("params", "calls", "events")}))
+        elif c["kind"] == "pipeline":
+            g = {k: c[k] for k in ("params", "calls", "fov")}
+            g["whitebalancing"] = spec.get("whitebalancing", True)
+            job["pipeline"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=fr, golden=g))
+        elif c["kind"] == "mainjs":
+            job["mainjs"].append(dict(name=c["name"], w=c["w"], h=c["h"], frames=fr, golden={k: c[k] for k in ("params", "calls", "fov")}))
+    with open(os.path.join(td, "facade_job.json"), "w") as f:
+        json.dump(job, f)
+    r = subprocess.run(["node", os.path.join(ROOT, "tests", "js", "parity_cpu.js"), os.path.join(td, "facade_job.json")], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    j = json.loads(r.stdout.strip().splitlines()[-1])
+    assert j["ok"], ("JS facade (state machines) vs reference", j["errors"][:6])
+    for f in cache.values():
+        os.remove(os.path.join(td, f))
+    return j["checked"], sum(len(c["frames"]) for k in ("facetrackr", "pipeline", "mainjs") for c in job[k])
+
+
 def lib_group(rects, min_neighbors):
     """the product's own host grouping (ht_group_rects, csrc/ht_hostpost.h: what the Python / C hosts and ht_detect_collect_best use)"""
     import ctypes as C
@@ -162,7 +248,7 @@ def check_product_host(td, res):
 
 def main():
     t0 = time.time()
-    tot = dict(detect=0, planes=0, raw=0, grouped=0, camshift=0, calls=0, post=0, sizes=set())
+    tot = dict(detect=0, planes=0, raw=0, grouped=0, camshift=0, calls=0, post=0, facade_checks=0, facade_frames=0, sizes=set())
     batch_no = 0
     with tempfile.TemporaryDirectory() as td:
         mg.OUT = td
@@ -170,6 +256,9 @@ def main():
             cases = [detect_case(batch_no * 100 + i) for i in range(16)] + [camshift_case(batch_no * 100 + i) for i in range(8)]
             for i in range(4):
                 cases += post_cases(batch_no * 100 + i)
+            if MOCK:
+                for i in range(2):
+                    cases += facade_cases(batch_no * 100 + i)
             sys.stdout.flush()
             sys.stderr.flush()
             keep, null = (os.dup(1), os.dup(2)), os.open(os.devnull, os.O_WRONLY)
@@ -188,12 +277,16 @@ def main():
             try:
                 check_product_host(td, res)
                 tot["post"] += 8
+                if MOCK:
+                    chk, frames = check_facade(td, cases, res)
+                    tot["facade_checks"] += chk
+                    tot["facade_frames"] += frames
             except AssertionError as e:
                 print("MISMATCH product host code vs reference, batch", batch_no, "seed", SEED, "\n", e)
                 return 1
             for spec, got in zip(cases, res["cases"]):
                 try:
-                    if got["kind"] in ("smoother", "headposition"):
+                    if got["kind"] in ("smoother", "headposition", "facetrackr", "pipeline", "mainjs"):
                         continue
                     if got["kind"] == "detect":
                         tg.check_detect_case(got, cascade)
@@ -214,7 +307,9 @@ def main():
           f"{len(tot['sizes'])} geometries; {tot['planes']} pyramid planes (size + CRC), {tot['raw']} raw rects incl. confidence bits, "
           f"{tot['grouped']} grouped faces, {tot['calls']} track() calls (window / x / y / width / height exact, angle to 1e-12): all identical.  "
           f"Product host code on the same reference output: ht_group_rects (C) and the JS facade's seq construction + ccv._group on every raw list, "
-          f"{tot['post']} random Smoother / headposition sequences through headtrackr_amd/js: all identical")
+          f"{tot['post']} random Smoother / headposition sequences through headtrackr_amd/js: all identical"
+          + (f"; facetrackr.Tracker / headtrackr.Tracker body / main.js loop on {tot['facade_frames']} frames of random sequences through the "
+             f"unchanged facade on the oracle-backed mock addon (tests/js/parity_cpu.js): {tot['facade_checks']} checks, all passed" if MOCK else ""))
     return 0
 
 

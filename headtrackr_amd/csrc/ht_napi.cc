@@ -65,7 +65,11 @@ napi_value throw_ht(napi_env env, ht_ctx *ctx, ht_status st, const char *where) 
 // thread-safe (include/headtrackr_hip.h) but detectAsync() runs on a libuv pool thread while the JS thread may call any
 // synchronous entry point on the same cached context (headtrackr.js shares one context per cascade): every entry point
 // takes `mu` for the duration of its C-ABI calls, so overlapping calls run one after the other, in lock-acquisition order.
+// The two kinds of handles the addon gives out are napi externals; a tag in front tells them apart, so that a device buffer passed where a
+// context is expected (or the other way round) is a TypeError, not a reinterpretation of the other struct's bytes.  Neither kind is ever freed.
+constexpr uint32_t SLOT_TAG = 0x4c535448u, DEVBUF_TAG = 0x42445448u;  // "HTSL", "HTDB"
 struct Slot {
+    uint32_t tag = SLOT_TAG;
     ht_ctx *ctx = nullptr;
     std::recursive_mutex mu;
     napi_env env = nullptr;  // the environment (main thread or a worker_threads Worker) that created the context: its cleanup hook destroys it
@@ -73,7 +77,7 @@ struct Slot {
 
 bool get_slot(napi_env env, napi_value v, Slot **out) {
     void *p = nullptr;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p) {
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || static_cast<Slot *>(p)->tag != SLOT_TAG) {
         napi_throw_type_error(env, nullptr, "expected a headtrackr_hip context");
         return false;
     }
@@ -96,6 +100,13 @@ bool lock_ctx(napi_env env, napi_value v, Locked *out) {
         napi_throw_error(env, nullptr, "context was destroyed");
         return false;
     }
+    return true;
+}
+
+// fewer arguments than the entry point needs: a TypeError, not a silent `undefined` (found by tests/js/addon_args.js)
+bool too_few(napi_env env, size_t argc, size_t need) {
+    if (argc >= need) return false;
+    napi_throw_type_error(env, nullptr, ("headtrackr_hip: " + std::to_string(need) + " arguments expected, " + std::to_string(argc) + " given").c_str());
     return true;
 }
 
@@ -220,7 +231,7 @@ napi_value Destroy(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     void *p = nullptr;
-    if (napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+    if (argc >= 1 && napi_get_value_external(env, argv[0], &p) == napi_ok && p && static_cast<Slot *>(p)->tag == SLOT_TAG) {
         Slot *slot = static_cast<Slot *>(p);
         std::lock_guard<std::recursive_mutex> lk(slot->mu);  // waits for an asynchronous job in flight on this context
         if (slot->ctx) ht_destroy(slot->ctx);
@@ -443,7 +454,7 @@ napi_value Grayscale(napi_env env, napi_callback_info info) {
     napi_value argv[5];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     FrameArgs a;
-    if (argc < 5 || !parse_frames(env, argv, &a)) return nullptr;
+    if (too_few(env, argc, 5) || !parse_frames(env, argv, &a)) return nullptr;
     ht_status st = ht_grayscale_batch(a.ctx, a.rgba, a.n, a.w, a.h, (size_t)a.w * a.h * 4);
     if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_grayscale_batch");
     return nullptr;
@@ -454,7 +465,7 @@ napi_value Whitebalance(napi_env env, napi_callback_info info) {
     napi_value argv[5];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     FrameArgs a;
-    if (argc < 5 || !parse_frames(env, argv, &a)) return nullptr;
+    if (too_few(env, argc, 5) || !parse_frames(env, argv, &a)) return nullptr;
     ht_status st = bind_host_frames(a);
     if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_upload_frames");
     napi_value ab, ta;
@@ -490,7 +501,7 @@ napi_value CamshiftInit(napi_env env, napi_callback_info info) {
     napi_value argv[7];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     FrameArgs a;
-    if (argc < 7 || !parse_frames(env, argv, &a)) return nullptr;
+    if (too_few(env, argc, 7) || !parse_frames(env, argv, &a)) return nullptr;
     int32_t first;
     napi_typedarray_type t;
     size_t n;
@@ -514,7 +525,7 @@ napi_value CamshiftTrack(napi_env env, napi_callback_info info) {
     napi_value argv[7];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     FrameArgs a;
-    if (argc < 7 || !parse_frames(env, argv, &a)) return nullptr;
+    if (too_few(env, argc, 7) || !parse_frames(env, argv, &a)) return nullptr;
     int32_t first, calc;
     if (!get_i32(env, argv[5], &first) || !get_i32(env, argv[6], &calc)) {
         napi_throw_type_error(env, nullptr, "camshiftTrack(ctx, rgba, n, w, h, first, calcAngles)");
@@ -656,13 +667,15 @@ napi_value HostAlloc(napi_env env, napi_callback_info info) {
 // a device buffer: freed explicitly (deviceFree) or, at the latest, when the JS handle is collected — through the context it was
 // allocated on, which the handle keeps alive
 struct DevBuf {
+    uint32_t tag = DEVBUF_TAG;
     Slot *slot = nullptr;  // Slots are never freed (a few bytes per context): a JS handle may outlive destroy()
     void *ptr = nullptr;
     size_t bytes = 0;
 };
 bool get_devbuf(napi_env env, napi_value v, DevBuf **out) {
     void *p = nullptr;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !static_cast<DevBuf *>(p)->ptr || !static_cast<DevBuf *>(p)->slot->ctx) {
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || static_cast<DevBuf *>(p)->tag != DEVBUF_TAG || !static_cast<DevBuf *>(p)->ptr ||
+        !static_cast<DevBuf *>(p)->slot->ctx) {
         napi_throw_type_error(env, nullptr, "expected a live device buffer (deviceAlloc) of a live context");
         return false;
     }
@@ -722,7 +735,7 @@ napi_value DeviceAlloc(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
     double bytes = 0;
-    if (argc < 2 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 2) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (napi_get_value_double(env, argv[1], &bytes) != napi_ok || !(bytes >= 1) || bytes > 2.5e11) {
         napi_throw_type_error(env, nullptr, "deviceAlloc(ctx, bytes)");
         return nullptr;
@@ -746,7 +759,7 @@ napi_value DeviceFree(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
     DevBuf *d = nullptr;
-    if (argc < 2 || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
+    if (too_few(env, argc, 2) || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
     ht_status st = ht_device_free(L.ctx, d->ptr);
     if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_device_free");  // e.g. the wrong context, or still bound elsewhere: the handle stays valid
     d->ptr = nullptr;
@@ -768,7 +781,7 @@ napi_value DeviceUpload(napi_env env, napi_callback_info info) {
     DevBuf *d = nullptr;
     uint8_t *src = nullptr;
     size_t len = 0, off = 0;
-    if (argc < 4 || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
+    if (too_few(env, argc, 4) || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
     if (!get_offset(env, argv[2], &off) || !get_bytes(env, argv[3], &src, &len) || off + len > d->bytes) {
         napi_throw_range_error(env, nullptr, "deviceUpload(ctx, dev, byteOffset, Uint8Array): outside the device buffer");
         return nullptr;
@@ -783,7 +796,7 @@ napi_value Upload(napi_env env, napi_callback_info info) {
     napi_value argv[5];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     FrameArgs a;
-    if (argc < 5 || !parse_frames(env, argv, &a)) return nullptr;
+    if (too_few(env, argc, 5) || !parse_frames(env, argv, &a)) return nullptr;
     ht_status st = bind_host_frames(a);
     if (st != HT_OK) return throw_ht(env, a.ctx, st, "ht_upload_frames");
     return nullptr;
@@ -797,7 +810,7 @@ napi_value BindDevice(napi_env env, napi_callback_info info) {
     DevBuf *d = nullptr;
     size_t off = 0, stride = 0;
     int32_t n = 0;
-    if (argc < 5 || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
+    if (too_few(env, argc, 5) || !lock_ctx(env, argv[0], &L) || !get_devbuf(env, argv[1], &d)) return nullptr;
     if (!get_offset(env, argv[2], &off) || !get_i32(env, argv[3], &n) || !get_offset(env, argv[4], &stride) || n <= 0 || off + (size_t)n * stride > d->bytes) {
         napi_throw_range_error(env, nullptr, "bindDevice(ctx, dev, byteOffset, n, frameStride): outside the device buffer");
         return nullptr;
@@ -815,7 +828,7 @@ napi_value UploadAsync(napi_env env, napi_callback_info info) {
     uint8_t *src = nullptr;
     size_t len = 0;
     int32_t n = 0;
-    if (argc < 3 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 3) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (!get_bytes(env, argv[1], &src, &len) || !get_i32(env, argv[2], &n) || n <= 0 || len % (size_t)n) {
         napi_throw_type_error(env, nullptr, "uploadAsync(ctx, Uint8Array rgba (n frames, ideally from hostAlloc), n)");
         return nullptr;
@@ -830,7 +843,7 @@ napi_value SwapFrames(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
-    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 1) || !lock_ctx(env, argv[0], &L)) return nullptr;
     ht_status st = ht_swap_frames(L.ctx);
     if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_swap_frames");
     return nullptr;
@@ -842,7 +855,7 @@ napi_value DetectEnqueue(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
     int32_t fl = 0;
-    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 1) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (argc > 1) get_i32(env, argv[1], &fl);
     ht_status st = ht_detect_enqueue(L.ctx, (uint32_t)fl);
     if (st != HT_OK) return throw_ht(env, L.ctx, st, "ht_detect_enqueue");
@@ -854,7 +867,7 @@ napi_value DetectCollect(napi_env env, napi_callback_info info) {
     napi_value argv[1];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
-    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 1) || !lock_ctx(env, argv[0], &L)) return nullptr;
     DetectJob j;
     j.n = ht_frames_enqueued(L.ctx);  // the batch in flight, not whatever is bound by now
     j.hits.resize(1u << 16);
@@ -874,7 +887,7 @@ napi_value CollectBest(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
     int32_t mn = 1, rq = -1;
-    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 1) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (argc > 1) get_i32(env, argv[1], &mn);
     if (argc > 2) get_i32(env, argv[2], &rq);
     const int32_t n = ht_frames_enqueued(L.ctx);
@@ -913,7 +926,7 @@ napi_value wb_common(napi_env env, napi_callback_info info, bool fused) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
     int32_t n = 0;
-    if (argc < 2 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 2) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (!get_i32(env, argv[1], &n) || n <= 0) {
         napi_throw_type_error(env, nullptr, "(ctx, n)");
         return nullptr;
@@ -948,7 +961,7 @@ napi_value CamshiftInitBound(napi_env env, napi_callback_info info) {
     void *p;
     napi_value ab;
     size_t off;
-    if (argc < 4 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 4) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (!get_i32(env, argv[1], &n) || !get_i32(env, argv[2], &first) || n <= 0 || napi_get_typedarray_info(env, argv[3], &t, &len, &p, &ab, &off) != napi_ok ||
         t != napi_int32_array || len < (size_t)n * 4) {
         napi_throw_type_error(env, nullptr, "camshiftInitBound(ctx, n, first, Int32Array rects[4n])");
@@ -966,7 +979,7 @@ napi_value CamshiftTrackBound(napi_env env, napi_callback_info info) {
     Locked L;
     int32_t n = 0, first = 0, calc = 1;
     bool fetch = true;
-    if (argc < 4 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 4) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (!get_i32(env, argv[1], &n) || !get_i32(env, argv[2], &first) || !get_i32(env, argv[3], &calc) || n <= 0) {
         napi_throw_type_error(env, nullptr, "camshiftTrackBound(ctx, n, first, calcAngles, fetch)");
         return nullptr;
@@ -985,7 +998,7 @@ napi_value CamshiftTrackCollect(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
     int32_t n = 0;
-    if (argc < 2 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 2) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (!get_i32(env, argv[1], &n) || n <= 0) {
         napi_throw_type_error(env, nullptr, "camshiftTrackCollect(ctx, n)");
         return nullptr;
@@ -1010,7 +1023,7 @@ napi_value CamshiftTrackSequence(napi_env env, napi_callback_info info) {
     void *p;
     napi_value ab;
     size_t off;
-    if (argc < 7 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 7) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (!get_i32(env, argv[1], &first) || !get_i32(env, argv[2], &n) || !get_i32(env, argv[3], &calc) || !get_devbuf(env, argv[4], &d)) return nullptr;
     if (napi_get_typedarray_info(env, argv[5], &t, &ncalls, &p, &ab, &off) != napi_ok || t != napi_float64_array || ncalls == 0 || ncalls > 100000 ||
         !get_offset(env, argv[6], &stride) || n <= 0) {
@@ -1042,7 +1055,7 @@ napi_value CamshiftSequenceCollect(napi_env env, napi_callback_info info) {
     Locked L;
     int32_t n = 0, ncalls = 0;
     bool out_all = false;
-    if (argc < 3 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 3) || !lock_ctx(env, argv[0], &L)) return nullptr;
     if (!get_i32(env, argv[1], &n) || !get_i32(env, argv[2], &ncalls) || n <= 0 || ncalls <= 0) {
         napi_throw_type_error(env, nullptr, "camshiftSequenceCollect(ctx, n, ncalls, outAll)");
         return nullptr;
@@ -1059,7 +1072,7 @@ napi_value ctx_counter(napi_env env, napi_callback_info info, int which) {
     napi_value argv[1];
     NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
     Locked L;
-    if (argc < 1 || !lock_ctx(env, argv[0], &L)) return nullptr;
+    if (too_few(env, argc, 1) || !lock_ctx(env, argv[0], &L)) return nullptr;
     napi_value v;
     const double x = which == 0 ? (double)ht_frames_bound(L.ctx) : which == 1 ? (double)ht_frames_enqueued(L.ctx) : (double)ht_graph_launches(L.ctx);
     NAPI_OK(napi_create_double(env, x, &v));

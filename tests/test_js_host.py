@@ -30,6 +30,19 @@ def test_facade_exports_and_host_grouping():
     assert out["abi"] == 2
 
 
+@pytest.mark.skipif(NODE is None, reason="node is not installed")
+def test_addon_argument_handling_never_crashes_or_swallows():
+    """the product addon (csrc/ht_napi.cc) under malformed calls, no GPU needed: ~11 000 calls with too few / wrong arguments end in a
+    JavaScript exception (never a crash, never a silent `undefined`: a run of this script found 21 entry points returning silently when
+    called with too few arguments; a context handle and a device-buffer handle are told apart by a tag, not reinterpreted)"""
+    _build()
+    r = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "addon_args.js")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-2000:])  # a crash would be a signal exit
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["ok"], out["errors"]
+    assert out["calls"] > 10000 and out["threw"] > 0.9 * out["calls"] - 700
+
+
 def _parity_job(tmp_path):
     """the golden vectors of the reference JS as a job for tests/js/parity_gpu.js (frames written as raw RGBA files)"""
     det, cam, ft = load_golden("detect.json"), load_golden("camshift.json"), load_golden("facetrackr.json")

@@ -219,3 +219,36 @@ def test_deep_kernel_atomic_result_is_untouched_until_waited_for():
                 issued += 1
         else:
             raise AssertionError("no covering s_waitcnt found")
+
+
+def test_every_export_rejects_null_arguments_without_crashing():
+    """"int status codes + ht_last_error, never exceptions" — and never a crash: every export of the header called with
+    all-zero arguments (NULL context, NULL buffers, zero sizes) in a child process, which must survive all 49 calls; the ht_status
+    functions must report an error (a negative status), the queries must return 0 / NULL."""
+    code = r'''
+import ctypes as C, re, sys
+sys.path.insert(0, %r)
+from headtrackr_amd import native
+L = native.lib()
+hdr = re.sub(r"/\*.*?\*/", "", open(%r).read(), flags=re.S)
+protos = re.findall(r"\n(\w[\w \*]*?)\b(ht_[a-z0-9_]+)\s*\(([^;]*?)\);", hdr)
+assert len(protos) >= 49, len(protos)
+for ret, name, args in protos:
+    n = 0 if args.strip() in ("void", "") else len(args.split(","))
+    f = getattr(L, name)
+    f.argtypes = None
+    f.restype = C.c_int32 if ("ht_status" in ret or "int32_t" in ret) else (C.c_uint64 if "uint64_t" in ret else C.c_void_p)
+    r = f(*([C.c_void_p(0)] * n))
+    if "ht_status" in ret:
+        assert r < 0, (name, r)
+    elif name in ("ht_abi_version",):
+        assert r == 2
+    elif name not in ("ht_last_error", "ht_destroy", "ht_host_free", "ht_device_count"):
+        assert not r, (name, r)
+print("survived", len(protos))
+''' % (ROOT, os.path.join(ROOT, "include", "headtrackr_hip.h"))
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().startswith("survived"), (r.returncode, r.stdout[-500:], r.stderr[-1500:])

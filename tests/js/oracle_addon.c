@@ -1,7 +1,7 @@
 /*
  * tests/js/oracle_addon.c — TEST INFRASTRUCTURE: the CPU oracle (oracle/ht_oracle.c) as a Node addon, so that the JavaScript
  * facade's HOST logic (facetrackr state machine, headtrackr.Tracker loop, debug overlay) can run on a box without a GPU:
- * tests/js/mock_addon.js implements the product addon's single-frame entry points on top of these five functions and
+ * tests/js/mock_addon.js implements the product addon's entry points on top of these six functions and
  * tests/js/parity_cpu.js replays the reference-JS golden vectors through headtrackr_amd/js/headtrackr.js with it.
  * Nothing under headtrackr_amd/ knows about this file; the product addon (csrc/ht_napi.cc) has no CPU path.
  *
@@ -146,11 +146,51 @@ static napi_value CsTrack(napi_env env, napi_callback_info info) {
     return out;
 }
 
+/* bestFace(rgba, w, h, grayInR, blob, interval, minNeighbors) -> Float64Array [x, y, width, height, confidence, neighbors, raw hits]:
+ * ccv.detect_objects(..., minNeighbors) + facetrackr's choice (facetrackr.js:157-165: strict '>', first maximum wins); no face: zeros,
+ * confidence -10000, neighbors 0 (facetrackr.js:239) */
+static napi_value BestFace(napi_env env, napi_callback_info info) {
+    ARGS(7);
+    uint8_t *rgba, *blob;
+    size_t len, blen;
+    int32_t w, h, gray, interval, mn;
+    if (!get_u8(env, argv[0], &rgba, &len) || !get_i32(env, argv[1], &w) || !get_i32(env, argv[2], &h) || !get_i32(env, argv[3], &gray) ||
+        !get_u8(env, argv[4], &blob, &blen) || !get_i32(env, argv[5], &interval) || !get_i32(env, argv[6], &mn))
+        return NULL;
+    if (len < (size_t)w * h * 4) {
+        napi_throw_error(env, NULL, "oracle_addon.bestFace: frame shorter than w * h * 4");
+        return NULL;
+    }
+    ho_cascade c;
+    int64_t cap = 1 << 16;
+    ho_hit *hits = (ho_hit *)malloc(sizeof(ho_hit) * (size_t)cap);
+    int64_t n = ho_detect_raw(rgba, w, h, gray, blob, blen, interval, hits, cap, NULL);
+    if (n < 0 || n > cap || ho_parse_cascade(blob, blen, &c) != 0) {
+        free(hits);
+        napi_throw_error(env, NULL, "oracle_addon.bestFace: ho_detect_raw failed");
+        return NULL;
+    }
+    ho_rect *seq = (ho_rect *)malloc(sizeof(ho_rect) * (size_t)(n + 1)), *grp = (ho_rect *)malloc(sizeof(ho_rect) * (size_t)(n + 1));
+    ho_hits_to_rects(hits, n, interval, (int)c.width, (int)c.height, seq);
+    int ng = mn > 0 ? ho_group(seq, (int)n, mn, grp) : 0;
+    void *p;
+    napi_value out = typed(env, napi_float64_array, 7, 8, &p);
+    double *d = (double *)p;
+    d[0] = d[1] = d[2] = d[3] = d[5] = 0, d[4] = -10000.0, d[6] = (double)n;
+    for (int k = 0; k < ng; k++)
+        if (k == 0 || grp[k].confidence > d[4])
+            d[0] = grp[k].x, d[1] = grp[k].y, d[2] = grp[k].width, d[3] = grp[k].height, d[4] = grp[k].confidence, d[5] = grp[k].neighbors;
+    free(hits);
+    free(seq);
+    free(grp);
+    return out;
+}
+
 static napi_value Init(napi_env env, napi_value exports) {
     const struct {
         const char *name;
         napi_callback fn;
-    } fns[] = {{"detectRaw", DetectRaw}, {"grayscale", Grayscale}, {"whitebalance", Whitebalance}, {"csInit", CsInit}, {"csTrack", CsTrack}};
+    } fns[] = {{"detectRaw", DetectRaw}, {"grayscale", Grayscale}, {"whitebalance", Whitebalance}, {"csInit", CsInit}, {"csTrack", CsTrack}, {"bestFace", BestFace}};
     for (size_t i = 0; i < sizeof(fns) / sizeof(fns[0]); i++) {
         napi_value fn;
         if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &fn) != napi_ok) return NULL;

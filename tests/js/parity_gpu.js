@@ -175,13 +175,6 @@ job.facetrackr.forEach(function (cs) {
 
 /* batch entry point (async): same frames in one call == per-frame results */
 (async function () {
-  if (job.cpu_mock) { /* tests/js/parity_cpu.js: the drop-in sections above on the oracle-backed mock addon; the batch / pipelined entry
-    points below exist only to drive the GPU and are not mocked */
-    out.cs_parity = (out.cs_exact || 0) + '/' + (out.cs_total || 0);
-    out.addon_calls = require(path.join(root, 'headtrackr_amd', 'js', 'headtrackr_hip.node')).calls;
-    console.log(JSON.stringify(out));
-    return;
-  }
   if (job.detect.length) {
     const same = job.detect.filter(function (c) { return c.w === 320 && c.h === 240 && c.interval === 5; }).slice(0, 6);
     const n = same.length, buf = new Uint8Array(n * 320 * 240 * 4);
@@ -290,5 +283,6 @@ job.facetrackr.forEach(function (cs) {
     }
   }
   out.cs_parity = (out.cs_exact || 0) + '/' + (out.cs_total || 0);
+  if (job.cpu_mock) out.addon_calls = require(path.join(root, 'headtrackr_amd', 'js', 'headtrackr_hip.node')).calls; /* tests/js/parity_cpu.js */
   console.log(JSON.stringify(out));
 })().catch(function (e) { out.ok = false; out.errors.push('exception: ' + e.stack); console.log(JSON.stringify(out)); });

@@ -92,10 +92,12 @@ def _build_oracle_addon():
 @pytest.mark.skipif(NODE is None or not os.path.exists("/usr/include/node/node_api.h"), reason="node / node_api.h not installed")
 def test_js_facade_host_logic_on_the_cpu_mock(tmp_path):
     """The UNCHANGED JavaScript facade (headtrackr.js + tracker.js) against the reference-JS golden vectors without a GPU: the product
-    addon is replaced by tests/js/mock_addon.js (its single-frame entry points on the CPU oracle), everything above the addon interface
-    is the product's code — seq construction, grouping, getWhitebalance, camshift.Tracker with its debug getters, the facetrackr WB -> VJ
-    -> CS state machine with its events, the headtrackr.Tracker loop (status events, Smoother, headposition) and the main.js debug overlay
-    (stroke calls + canvas pixels), at every golden frame size."""
+    addon is replaced by tests/js/mock_addon.js (its entry points on the CPU oracle), everything above the addon interface is the
+    product's code — seq construction, grouping, getWhitebalance, camshift.Tracker with its debug getters, the facetrackr WB -> VJ -> CS
+    state machine with its events, the headtrackr.Tracker loop (status events, Smoother, headposition), the main.js debug overlay
+    (stroke calls + canvas pixels), and the host side of detect_objects_batch (async, sharded + gathered) and ccv.DeviceBatch (detect,
+    detectBest over three contexts with re-enqueue, fused whitebalance, trackSequence, pinned ingest) — the WHOLE job of the GPU run,
+    at every golden frame size."""
     _build_oracle_addon()
     job = _parity_job(tmp_path)
     job["cpu_mock"] = True
@@ -105,16 +107,66 @@ def test_js_facade_host_logic_on_the_cpu_mock(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["ok"], out["errors"]
-    assert out["checked"] > 1700
+    assert out["checked"] > 2000
     exact, total = (int(v) for v in out["cs_parity"].split("/"))
     assert total > 0 and exact == total
     calls = out["addon_calls"]  # the facade really went through the addon interface
     for k in ("createContext", "setGeometry", "upload", "grayscale", "detect", "detectEnqueue", "detectCollect", "whitebalance",
-              "whitebalanceBound", "camshiftReserve", "camshiftInitBound", "camshiftTrackBound"):
+              "whitebalanceBound", "camshiftReserve", "camshiftInitBound", "camshiftTrackBound", "detectAsync", "allgatherBest",
+              "deviceAlloc", "deviceUpload", "bindDevice", "collectBest", "detectWhitebalance", "camshiftTrackSequence", "uploadAsync",
+              "swapFrames", "hostAlloc", "hostFree", "deviceFree", "destroy"):
         assert calls.get(k, 0) > 0, (k, calls)
     # every frame size was announced through setGeometry (V8-computed level sizes, headtrackr.js levelDims): the addon never had to
     # re-build a geometry on its own (this run found getWhitebalance skipping that step)
     assert calls.get("implicitGeometry", 0) == 0, calls
+
+
+@pytest.mark.skipif(NODE is None or not os.path.exists("/usr/include/node/node_api.h"), reason="node / node_api.h not installed")
+def test_c5_loop_from_node_on_the_cpu_mock(cascade, tmp_path):
+    """tests/js/c5_stream.js — the C5 loop of the JavaScript host (ccv.DeviceBatch: resident frame sets, detect step enqueued behind the
+    outstanding track steps, initTracker on the floored best faces, enqueue-only track steps collected from the ring) — UNCHANGED, on the
+    oracle-backed mock addon: 2 feeds of 1920x1080, 35 steps (detect at steps 0 and 30).  Every step's result must be what the reference's
+    per-feed loop produces (oracle): best faces, floored rects, every track object in order.  This checks the host-side sequencing — which
+    set is bound when, which step a collected result belongs to; the kernels are checked by tests/test_gpu_c5.py on the GPU."""
+    import math
+
+    import numpy as np
+
+    from oracle import ht_oracle as ho
+
+    _build_oracle_addon()
+    W, H, nuniq, K, steps = 1920, 1080, 8, 2, 35
+    uniq = synth.stream_feed_frames(nuniq, W, H, 0)
+    raw, outf = tmp_path / "uniq.raw", tmp_path / "out.json"
+    uniq.tofile(str(raw))
+    r = subprocess.run([NODE, "-r", os.path.join(ROOT, "tests", "js", "mock_preload.js"), os.path.join(ROOT, "tests", "js", "c5_stream.js"), "parity",
+                        str(raw), str(nuniq), str(K), str(steps), str(outf)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    os.unlink(str(raw))
+    got = json.loads(outf.read_text())
+    assert len(got["steps"]) == steps and got["feeds"] == K
+    oracles, tracked = [None] * K, 0
+    for i, s in enumerate(got["steps"]):
+        assert s["step"] == i
+        if i % 30 == 0:
+            best = np.array(s["best"]).reshape(K, 6)
+            for f in range(K):
+                u = synth.stream_frame_index(i, f, nuniq)
+                wb = ho.best_faces(uniq[u : u + 1], cascade.blob, 1)[0]
+                assert list(best[f]) == [wb["x"], wb["y"], wb["width"], wb["height"], wb["confidence"], float(wb["neighbors"])], (i, f)
+                rect = tuple(int(math.floor(v)) for v in best[f][:4])
+                assert tuple(s["rects"][4 * f : 4 * f + 4]) == rect
+                oracles[f] = ho.Camshift(True)
+                oracles[f].init_tracker(uniq[u], rect)
+        else:
+            t = np.array(s["track"]).reshape(K, 9)
+            for f in range(K):
+                sw, to = oracles[f].track(uniq[synth.stream_frame_index(i, f, nuniq)])
+                assert [int(v) for v in t[f][5:9]] == list(sw), (i, f)
+                assert [t[f][0], t[f][1], t[f][2], t[f][3]] == [to["x"], to["y"], to["width"], to["height"]], (i, f)
+                assert abs(t[f][4] - to["angle"]) <= 1e-12, (i, f)
+                tracked += 1
+    assert tracked == K * (steps - 2)
 
 
 @pytest.mark.gpu

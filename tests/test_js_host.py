@@ -169,6 +169,29 @@ def test_c5_loop_from_node_on_the_cpu_mock(cascade, tmp_path):
     assert tracked == K * (steps - 2)
 
 
+@pytest.mark.skipif(NODE is None or not os.path.exists("/usr/include/node/node_api.h"), reason="node / node_api.h not installed")
+def test_js_host_benchmark_script_on_the_cpu_mock(tmp_path):
+    """tests/js/bench_host.js (bench.py's js_host sub-record) unchanged on the oracle-backed mock addon: both batch paths see the same
+    faces, and the drop-in facetrackr.Tracker ends where the unmodified reference JS ends on the same frames (where oracle/_ref exists).
+    Speeds mean nothing here; the GPU run of the same script is tests/test_js_host.py::test_js_host_benchmark_runs."""
+    import numpy as np
+
+    _build_oracle_addon()
+    W, H, n, nt = 320, 240, 16, 30
+    c2, tr = tmp_path / "c2.raw", tmp_path / "track.raw"
+    synth.mixed_batch(n, W, H, seed0=1234).tofile(str(c2))
+    np.stack([synth.face_frame(W, H, [(90 + 2 * k, 50 + k, 96)]) for k in range(nt)]).tofile(str(tr))
+    r = subprocess.run([NODE, "-r", os.path.join(ROOT, "tests", "js", "mock_preload.js"), os.path.join(ROOT, "tests", "js", "bench_host.js"), "0.1",
+                        str(c2), str(n), str(tr), str(nt)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["batch_device"]["frames_with_faces"] == out["batch_host"]["frames_with_faces"] > 0
+    t = out["tracker"]
+    assert t["vj_calls"] >= 2 and t["cs_calls"] >= 50 and t["after_60_calls"][4] == "CS"
+    if "tracker_reference_js" in out:
+        assert t["same_result_as_reference"] is True, (t["after_60_calls"], out["tracker_reference_js"]["after_60_calls"])
+
+
 @pytest.mark.gpu
 @pytest.mark.skipif(NODE is None, reason="node is not installed")
 def test_js_host_parity_on_gpu(tmp_path):

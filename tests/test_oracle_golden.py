@@ -124,3 +124,50 @@ def test_four_instruction_histogram_bin_equals_the_reference_formula_exhaustivel
         assert got.dtype == np.uint32 and np.array_equal(got, want), hex(alpha)
         mul = (t.astype(np.uint64) * 0x1001 & 0xFFFFFFFF).astype(np.uint32)  # the v_mul_u32_u24 form of t + (t << 12)
         assert np.array_equal(mul, t + (t << np.uint32(12)))
+
+
+def test_integer_stage_decisions_equal_the_sequential_binary64_sums(cascade):
+    """DESIGN.md §2.1 "Exact decisions without the reference's summation order": the kernels decide a stage with integers
+    (2 F < T', F = sum of alpha[2k+1] * 1e8 over the fired features, T' = threshold * 1e8 + sum of all of them) instead of ccv.js:189-225's
+    sequential binary64 sum.  The argument needs (1) every alpha / threshold to be a decimal with <= 8 fractional digits, (2) alpha[2k] ==
+    -alpha[2k+1], (3) the worst-case rounding error of a sequential binary64 sum to stay far below the 1e-8 grid.  All three are checked on
+    the shipped cascade, and the rule itself is compared with the sequential sum on 6 000 random fire patterns per stage (400 of them walked towards the threshold) (plus the
+    all-fire / none-fire corners): the decisions agree wherever 2 F != T' (an exact tie takes the sequential path in the kernels)."""
+    rng = np.random.default_rng(12)
+    u = 2.0 ** -53
+    for si, st in enumerate(cascade.stages):
+        first, count, thr = int(st["first"]), int(st["count"]), float(st["threshold"])
+        alpha = cascade.features["alpha"][first : first + count].astype(np.float64)  # [count, 2]
+        assert np.array_equal(alpha[:, 0], -alpha[:, 1]), si  # (2)
+        A = np.rint(alpha[:, 1] * 1e8).astype(np.int64)
+        assert np.all(np.abs(alpha[:, 1] * 1e8 - A) < 1e-6) and abs(thr * 1e8 - round(thr * 1e8)) < 1e-6, si  # (1)
+        # the decimal literal nearest to A / 1e8 is the stored double itself (cascade.js holds the decimals; JS parses them to these doubles)
+        assert np.array_equal(A.astype(np.float64) / 1e8, alpha[:, 1]) and round(thr * 1e8) / 1e8 == thr, si
+        S, T = int(A.sum()), int(round(thr * 1e8))
+        Tp = T + S
+        # (3) |fl(sum) - exact| <= gamma_n * sum|alpha| (Higham), + each alpha's and the threshold's own representation error (<= u * |value|)
+        n = count
+        bound = (n * u / (1 - n * u)) * float(np.abs(alpha[:, 1]).sum()) + u * float(np.abs(alpha[:, 1]).sum()) + u * abs(thr)
+        assert bound < 1e-10, (si, bound)  # two orders of magnitude below half a grid step (0.5e-8)
+        pats = rng.random((6000, count)) < rng.random((6000, 1))  # fire probabilities from 0 to 1
+        pats[0], pats[1] = True, False
+        # patterns whose sums land near the threshold: start from a random pattern and greedily walk towards T'
+        for k in range(2, 400):
+            f = pats[k]
+            for _ in range(3 * count):
+                d = Tp - 2 * int(A[f].sum())
+                j = int(rng.integers(0, count))
+                if (d > 0) != f[j] and abs(d - (2 * int(A[j]) if not f[j] else -2 * int(A[j]))) < abs(d):
+                    f[j] = not f[j]
+        ties = 0
+        for f in pats:
+            s = 0.0
+            for k in range(count):  # ccv.js:189-220: sum += alpha[k * 2 + fire], in feature order
+                s += alpha[k, 1] if f[k] else alpha[k, 0]
+            F2 = 2 * int(A[f].sum())
+            if F2 == Tp:
+                ties += 1
+                continue
+            assert (s < thr) == (F2 < Tp), (si, s, thr, F2, Tp)
+            assert abs(s - (F2 - S) / 1e8) < 1e-10
+        assert ties < len(pats)

@@ -171,3 +171,64 @@ def test_integer_stage_decisions_equal_the_sequential_binary64_sums(cascade):
             assert (s < thr) == (F2 < Tp), (si, s, thr, F2, Tp)
             assert abs(s - (F2 - S) / 1e8) < 1e-10
         assert ties < len(pats)
+
+
+def test_resample_binary32_estimate_stays_inside_its_error_budget():
+    """ht_pyramid.hip evaluates every pyramid pixel in binary32 first (three fused multiply-adds) and trusts the rounded estimate only when
+    it is at least RS_EPS away from a rounding boundary; otherwise the declared binary64 sequence (oracle/canvas_shim.js resample) decides.
+    The source bounds |estimate - declared| by 6.9e-5 < RS_EPS = 2^-13 analytically; here the same two computations are restated with numpy
+    (fma32(a, b, c) = fl32(a * b + c) with the product exact in binary64) on 24 M random tap / weight combinations, a third of them steered
+    next to a rounding boundary: the distance stays inside the budget, and wherever the kernel would trust the estimate its rounding equals
+    the declared value's round-half-even."""
+    import os
+    import re
+
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "headtrackr_amd", "csrc", "ht_pyramid.hip")).read()
+    m = re.search(r"constexpr float RS_EPS = 1\.0f / (\d+)\.0f;", src)
+    assert m, "RS_EPS moved"
+    eps = 1.0 / int(m.group(1))
+    assert "__builtin_fmaf(ctf[k], p01 - p00, p00)" in src and "__builtin_fmaf(rtf[q], bot - top, top)" in src  # what is restated below
+    f32, f64 = np.float32, np.float64
+
+    def fma32(a, b, c):  # a, b, c binary32; a * b is exact in binary64 (24 + 24 bits), one more rounding to binary32
+        return (a.astype(f64) * b.astype(f64) + c.astype(f64)).astype(f32)
+
+    rng = np.random.default_rng(2026)
+    worst, trusted, total = 0.0, 0, 0
+    for rep in range(12):
+        n = 2_000_000
+        p = rng.integers(0, 256, (4, n)).astype(f64)  # p00, p01, p10, p11
+        if rep % 3 == 1:  # smooth neighbourhoods (natural images): taps within +-6 of each other
+            p = np.clip(p[0] + rng.integers(-6, 7, (4, n)), 0, 255).astype(f64)
+        tx, ty = rng.random(n), rng.random(n)
+        if rep % 4 == 3:  # weights as the geometry produces them: t = frac((j + 0.5) * (s / d) - 0.5)
+            s, d, j = rng.integers(2, 2000, n).astype(f64), rng.integers(1, 2000, n).astype(f64), rng.integers(0, 2000, n).astype(f64)
+            fx = (j + 0.5) * (s / d) - 0.5
+            tx = np.clip(fx - np.floor(fx), 0.0, 1.0)
+        if rep % 3 == 2:  # steer the declared value next to k + 0.5: solve for ty on the exact bilinear form
+            top_e, bot_e = p[0] + tx * (p[1] - p[0]), p[2] + tx * (p[3] - p[2])
+            lo, hi = np.minimum(top_e, bot_e), np.maximum(top_e, bot_e)
+            k = np.floor(lo + rng.random(n) * (hi - lo)) + 0.5
+            ok = (k > lo) & (k < hi) & (hi - lo > 1e-9)
+            ty = np.where(ok, np.clip((k - top_e) / np.where(ok, bot_e - top_e, 1.0) + rng.normal(0, 2e-5, n), 0.0, 1.0 - 2.0 ** -53), ty)
+        # declared binary64 sequence (canvas_shim.js:165-176 / rs_pixel_f64)
+        ux, uy = 1.0 - tx, 1.0 - ty
+        top = p[0] * ux + p[1] * tx
+        bot = p[2] * ux + p[3] * tx
+        v = top * uy + bot * ty
+        want = np.rint(v)  # numpy rounds half to even like the Uint8ClampedArray store
+        # binary32 estimate of the kernels
+        p32 = p.astype(f32)
+        ctf, rtf = tx.astype(f32), ty.astype(f32)
+        top32 = fma32(ctf, p32[1] - p32[0], p32[0])
+        bot32 = fma32(ctf, p32[3] - p32[2], p32[2])
+        v32 = fma32(rtf, (bot32 - top32).astype(f32), top32)
+        dist = np.abs(v32.astype(f64) - v)
+        worst = max(worst, float(dist.max()))
+        r32 = np.rint(v32)
+        trust = np.abs(v32 - r32) < f32(0.5 - eps)
+        assert np.array_equal(r32[trust].astype(f64), want[trust]), rep
+        trusted += int(trust.sum())
+        total += n
+    assert worst < eps and worst < 6.9e-5 * 1.05, worst  # inside RS_EPS, and inside the analytic bound of the source
+    assert trusted > 0.5 * total

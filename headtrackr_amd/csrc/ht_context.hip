@@ -284,6 +284,7 @@ static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) 
         else if (key == "rs_notail") c->rs_notail = iv != 0;
         else if (key == "rs_nofast") c->rs_nofast = iv != 0;
         else if (key == "rs_nosort") c->rs_nosort = iv != 0;
+        else if (key == "rs_bands") c->rs_bands = iv != 0;
         else if (key == "rs_gennames") c->rs_gennames = iv != 0;
         else if (key == "rs_minwg") c->rs_min_wgs = std::max(1, iv);
         else if (key == "rs_k") c->dbg_rs_k = iv;
@@ -641,6 +642,17 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
                         t.ex_ya = ht_host_tap(Y0, j.ry, j.sh, j.sy).a;
                         t.ex_sw16 = (ht_host_tap(X0 + ncols - 1, j.rx, j.sw, j.sx).b - t.ex_xa) / 16 + 1;
                         t.ex_sh = ht_host_tap(Y0 + nrows - 1, j.ry, j.sh, j.sy).b - t.ex_ya + 1;
+                        // k_resample_bands: the source rows of each wavefront's quarter of the tile (rows beyond the drawn ones read the
+                        // last drawn row's taps, as in the kernel)
+                        bool fit = t.ex_sw16 * 16 <= 160;
+                        for (int w = 0; w < 4; w++) {
+                            const int r0 = std::min(4 * np * w, nrows - 1), r1 = std::min(4 * np * (w + 1) - 1, nrows - 1);
+                            const int bya = ht_host_tap(Y0 + r0, j.ry, j.sh, j.sy).a - t.ex_ya;
+                            const int bsh = ht_host_tap(Y0 + r1, j.ry, j.sh, j.sy).b - (t.ex_ya + bya) + 1;
+                            if (bya < 0 || bya > 255 || bsh < 1 || bsh > HT_RSB_ROWS) fit = false;
+                            t.band_ya4 |= (uint32_t)(bya & 0xff) << (8 * w), t.band_sh4 |= (uint32_t)(bsh & 0xff) << (8 * w);
+                        }
+                        if (fit) t.pad |= 4;
                     }
                     tiles.push_back(t);
                 }

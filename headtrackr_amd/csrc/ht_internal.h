@@ -129,7 +129,11 @@ struct HtResampleJob {
     // workgroup before its first load can be issued)
     int32_t ex_xa, ex_ya;    // first source column (rounded down to 16) / row
     int32_t ex_sw16, ex_sh;  // 16-byte chunks per source row, source rows
+    // k_resample_bands: wavefront w of the tile owns destination rows [4 np w, 4 np (w + 1)) and the source rows they touch — byte w of
+    // band_ya4 = first row relative to ex_ya, byte w of band_sh4 = rows; pad bit 2 says that all four fit a band (<= HT_RSB_ROWS rows)
+    uint32_t band_ya4, band_sh4;
 };
+constexpr int HT_RSB_ROWS = 24;  // k_resample_bands: source rows per wavefront band (4 KB of the 160-byte LDS pitch, one spare row)
 
 // One scan scale (ccv.js:154-160) and its tiling.
 struct HtScanScale {
@@ -295,6 +299,7 @@ struct ht_ctx {
     int dbg_rs_k = 0;  // option rs_k: frames per k_resample workgroup, forced (any value)
     int rs_group = 8;  // k_resample: frames per workgroup at most (option rs_group)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
+    bool rs_bands = false;  // option rs_bands: the pyramid generations run k_resample_bands (LDS-DMA into wave-private source bands) instead of k_resample
 
     // frames
     uint8_t *d_frames_own = nullptr;

@@ -630,6 +630,224 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
     }
 }
 
+// k_resample_bands (round 6): the same tiles, pixels and arithmetic as k_resample with the source staged by LDS-DMA into WAVE-PRIVATE bands.
+//
+// k_resample's frame iteration stages the next tile through 12 VGPRs per thread and needs two workgroup barriers (everybody done reading
+// -> registers to LDS -> everybody done writing); its phase stamps (profiles/r05_rs_phases_c2.txt) put 2 580 of an iteration's 5 708 cycles
+// into "load wait + registers -> LDS + barrier", with the four wavefronts reaching barrier 1 spread over ~1 190 cycles.  Here a wavefront owns
+// a contiguous quarter of the tile's destination rows (4 * np rows: np passes of 4 rows x 16 column groups) and with it the band of source
+// rows those rows touch (<= 24 rows of the 160-byte LDS pitch = 4 KB per wavefront; neighbouring bands overlap by 1 - 2 rows, which are
+// fetched twice).  A band is filled by four `buffer_load_dwordx4 ... lds` instructions (gfx950: 16 bytes per lane, 1 KB per instruction,
+// M0 = the band's LDS address; lanes outside the band are masked off) — no staging registers, no ds_write — and nobody else ever reads it:
+// the frame loop has NO workgroup barrier, a wavefront only waits for its own loads (s_waitcnt vmcnt) while the CU's other wavefronts
+// compute.  16 KB of bands + 3 KB of tap tables per workgroup and <= 64 VGPRs: 8 workgroups per CU (k_resample: 7 by registers).
+// The host fills in each tile record's band extents (ht_context.hip, the binary64 operations of rs_tap); a tile whose bands do not fit takes
+// the HBM-tap path exactly like k_resample's.
+#ifndef HT_RSB_WPS
+#define HT_RSB_WPS 8
+#endif
+constexpr int RSB_BAND = 4096;  // LDS bytes per wavefront = four 1 KB LDS-DMA instructions = 25.6 rows of RS_SP bytes
+typedef __attribute__((address_space(3))) void rs_lds_void;
+template <int RPT>
+__global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResampleJob *__restrict__ tiles, uint8_t *__restrict__ arena,
+                                                                    uint64_t arena_stride, uint32_t blocks_per_frame, uint32_t ngroups,
+                                                                    uint32_t nframes, uint32_t group_frames) {
+    constexpr int TH = 16 * RPT;
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[4 * RSB_BAND];
+    __shared__ RsTap s_col[RS_TW], s_row[TH];
+    uint32_t gidx, blk;
+    if (!xcd_item(blocks_per_frame, ngroups, &gidx, &blk)) return;
+    const HtResampleJob J = tiles[blk];
+    const uint32_t f0 = gidx * group_frames, f1 = min(f0 + group_frames, nframes);
+    const int tid = (int)threadIdx.x;
+    const int np = (int)J.np;
+    const int X0 = (int)J.bx * RS_TW, Y0 = (int)J.pass0 * 16;
+    uint8_t *frame = arena + (uint64_t)f0 * arena_stride;
+    const int ncols = min(RS_TW, J.dw - X0), nrows = min(16 * np, J.dh - Y0);
+    const uint32_t mode = J.pad;  // bit 0: 2x2 box mean, bit 1: binary64 everywhere, bit 2: the four bands fit (host)
+    if ((mode & 4u) && ncols > 0 && nrows > 0) {
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63;
+        const int xa = J.ex_xa, sw16 = J.ex_sw16;
+        const int yaw = J.ex_ya + (int)((J.band_ya4 >> (8 * w)) & 0xffu);  // first source row of this wavefront's band
+        const int bsh = (int)((J.band_sh4 >> (8 * w)) & 0xffu);             // ... and its rows (<= 24)
+        uint8_t *const band = s_src + w * RSB_BAND;
+        // lane -> 16-byte chunk of the band: instruction i fills chunks [64 i, 64 i + 64), chunk c = row c / 10, column c % 10
+        uint32_t voff[4];
+        bool on[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int c = i * 64 + l, row = (c * 205) >> 11, col = c - row * 10;
+            on[i] = col < sw16 && row < bsh;
+            voff[i] = J.src_off + (uint32_t)((yaw + row) * J.src_stride + xa + 16 * col);
+        }
+        uint64_t fbase = reinterpret_cast<uint64_t>(frame);
+#define RS_FRAME_RSRC(base_) __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(base_), 0, (int)0xffffffffu, 0x00020000)
+#define RSB_DMA(fr_, soff_)                                                                                                              \
+    do {                                                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) if (on[i])                                                                         \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(fr_, (rs_lds_void *)(band + i * 1024), 16, voff[i], soff_, 0, 0);                   \
+    } while (0)
+        {
+            const __amdgpu_buffer_rsrc_t fr = RS_FRAME_RSRC(fbase);
+            RSB_DMA(fr, 0u);  // the first frame's bands: in flight while the tap tables are computed
+            if (tid < ncols) s_col[tid] = rs_tap(X0 + tid, J.rx, J.sw, J.sx);
+            if (tid >= 64 && tid - 64 < nrows) s_row[tid - 64] = rs_tap(Y0 + tid - 64, J.ry, J.sh, J.sy);
+        }
+        __syncthreads();  // tap tables (and, vmcnt(0), this wavefront's band): the only workgroup barrier
+        const int cbase = (l & 15) * 4, x0 = X0 + cbase;
+        const int yt = Y0 + 4 * np * w + (l >> 4);  // this thread's rows: yt, yt + 4, ... (np of them)
+        const int npx = min(4, J.dw - x0);
+        int ia[4];
+        float ctf[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const RsTap *ct = &s_col[min(cbase + k, ncols - 1)];
+            ia[k] = ct->a - xa, ctf[k] = (float)ct->t;
+        }
+        uint32_t one = 1u;
+        asm volatile("" : "+s"(one));  // see RS_LD1
+        const float thr = (mode & 2u) ? -1.0f : 0.5f - RS_EPS;
+        const int dh = J.dh, ch = J.ch, dst_stride = J.dst_stride;
+        const uint32_t doff = J.dst_off + (uint32_t)(yt * dst_stride + x0);
+        const uint32_t pxmask = npx >= 4 ? 0xffffffffu : (npx <= 0 ? 0u : ((1u << (8 * npx)) - 1u));
+        const int ia8 = npx > 0 ? ia[0] : 0;
+        auto frames = [&](auto NPc, auto BOXc) {
+            constexpr int NP = decltype(NPc)::value;
+            constexpr bool BOX = decltype(BOXc)::value;
+            uint32_t roff[NP];
+            float rtf[NP];
+            bool st[NP], rv[NP];
+#pragma unroll
+            for (int q = 0; q < NP; q++) {
+                const int y = yt + 4 * q;
+                const RsTap *ry = &s_row[min(y - Y0, nrows - 1)];
+                roff[q] = (uint32_t)((ry->a - yaw) * RS_SP + w * RSB_BAND);
+                rtf[q] = (float)ry->t;
+                rv[q] = y < dh;
+                st[q] = y < ch && x0 < dst_stride;
+            }
+            for (uint32_t f = f0; f < f1; f++) {
+                asm volatile("" : "+s"(fbase));
+                const __amdgpu_buffer_rsrc_t fr = RS_FRAME_RSRC(fbase);
+                fbase += arena_stride;
+#pragma unroll
+                for (int q = 0; q < NP; q++) asm volatile("" : "+v"(roff[q]));
+                uint32_t o[NP];
+                if (BOX) {
+#pragma unroll
+                    for (int q = 0; q < NP; q++) {
+                        const uint8_t *row = s_src + roff[q] + ia8;
+                        const uint2 A = *reinterpret_cast<const uint2 *>(row), B = *reinterpret_cast<const uint2 *>(row + RS_SP);
+                        uint32_t oq = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t a = k < 2 ? A.x : A.y, b = k < 2 ? B.x : B.y;
+                            const uint32_t g = __builtin_amdgcn_perm(b, a, (k & 1) ? 0x07060302u : 0x05040100u);
+                            const uint32_t sum = __builtin_amdgcn_sad_u8(g, 0u, 0u);
+                            oq = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf((float)sum * 0.25f), k, oq);
+                        }
+                        o[q] = rv[q] ? (oq & pxmask) : 0u;
+                    }
+                } else {
+                    uint32_t T[16];
+#pragma unroll
+                    for (int q = 0; q < NP; q++) {
+                        const uint8_t *row_ = s_src + roff[q];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint8_t *p_ = row_ + ia[k];
+                            T[4 * k] = p_[0], T[4 * k + 1] = RS_LD1(p_ + 1), T[4 * k + 2] = p_[RS_SP], T[4 * k + 3] = RS_LD1(p_ + RS_SP + 1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        float d[4];
+                        uint32_t oq = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const float p00 = (float)T[4 * k], p01 = (float)T[4 * k + 1], p10 = (float)T[4 * k + 2], p11 = (float)T[4 * k + 3];
+                            const rs_f2 lo2 = {p00, p10}, hi2 = {p01, p11}, ct2 = {ctf[k], ctf[k]};
+                            const rs_f2 tb = __builtin_elementwise_fma(ct2, hi2 - lo2, lo2);
+                            const float top = tb.x, bot = tb.y;
+                            const float v = __builtin_fmaf(rtf[q], bot - top, top);
+                            const float r = __builtin_rintf(v);
+                            d[k] = v - r;
+                            oq = __builtin_amdgcn_cvt_pk_u8_f32(r, k, oq);
+                        }
+                        const float dmq = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(d[0]), __builtin_fabsf(d[1])), __builtin_fmaxf(__builtin_fabsf(d[2]), __builtin_fabsf(d[3])));
+                        if (dmq >= thr) {  // rare: the declared binary64 sequence next to a rounding boundary (see k_resample)
+                            uint32_t roff_f = roff[q];
+                            int yrel = yt - Y0, cb = cbase;
+                            asm volatile("" : "+v"(roff_f), "+v"(yrel), "+v"(cb));
+                            const RsTap *ry = &s_row[min(yrel + 4 * q, nrows - 1)];
+                            const uint8_t *rowf = s_src + roff_f;
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                if (__builtin_fabsf(d[k]) >= thr) {
+                                    const RsTap *ct = &s_col[min(cb + k, ncols - 1)];
+                                    oq &= ~(0xffu << (8 * k));
+                                    oq |= rs_pixel_f64(rowf + ia[k], rowf + ia[k] + one, ct->u, ct->t, ry->u, ry->t) << (8 * k);
+                                }
+                            }
+                        }
+                        o[q] = rv[q] ? (oq & pxmask) : 0u;
+                    }
+                }
+                if (f + 1 < f1) {
+                    // every LDS read of this frame's band has returned (o[] depends on all of them): the band may be overwritten.  The wait
+                    // below is for the DMA alone — this frame's stores are issued behind it, the previous frame's are a pixel phase old.
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    RSB_DMA(fr, (uint32_t)arena_stride);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int q = 0; q < NP; q++)
+                    if (st[q]) __builtin_amdgcn_raw_buffer_store_b32(o[q], fr, doff, (uint32_t)(4 * q * dst_stride), 0);
+            }
+        };
+        using std::integral_constant;
+        if (mode & 1u) {
+            switch (np) {
+                case 1: frames(integral_constant<int, 1>{}, integral_constant<bool, true>{}); break;
+                case 2: frames(integral_constant<int, 2>{}, integral_constant<bool, true>{}); break;
+                case 3: frames(integral_constant<int, 3>{}, integral_constant<bool, true>{}); break;
+                default: frames(integral_constant<int, RPT>{}, integral_constant<bool, true>{}); break;
+            }
+        } else {
+            switch (np) {
+                case 1: frames(integral_constant<int, 1>{}, integral_constant<bool, false>{}); break;
+                case 2: frames(integral_constant<int, 2>{}, integral_constant<bool, false>{}); break;
+                case 3: frames(integral_constant<int, 3>{}, integral_constant<bool, false>{}); break;
+                default: frames(integral_constant<int, RPT>{}, integral_constant<bool, false>{}); break;
+            }
+        }
+#undef RSB_DMA
+#undef RS_FRAME_RSRC
+        return;
+    }
+    // nothing drawn in this tile (transparent black), or bands that do not fit: taps straight from HBM, k_resample's thread -> pixel map
+    const HtResampleJob &Jm = tiles[blk];
+    const int x0 = X0 + (tid & 15) * 4, yt = Y0 + (tid >> 4);
+    const int npx = min(4, Jm.dw - x0);
+    const bool drawn = ncols > 0 && nrows > 0;
+    RsTap cx[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) cx[k] = rs_tap(min(x0 + k, X0 + max(ncols, 1) - 1), Jm.rx, Jm.sw, Jm.sx);
+    for (uint32_t f = f0; f < f1; f++, frame += arena_stride) {
+        const uint8_t *src = frame + Jm.src_off;
+        int ytl = yt;
+        asm volatile("" : "+v"(ytl));
+#pragma unroll
+        for (int q = 0; q < RPT; q++) {
+            const int y = ytl + 16 * q;
+            uint32_t o = 0;
+            if (drawn && q < np && y < Jm.dh && npx > 0) {
+                const RsTap ry = rs_tap(y, Jm.ry, Jm.sh, Jm.sy);
+                o = rs_pixels4<const uint8_t *>(src + (size_t)ry.a * Jm.src_stride, src + (size_t)ry.b * Jm.src_stride, cx, ry, 0, npx);
+            }
+            if (q < np && y < Jm.ch && x0 < Jm.dst_stride) *reinterpret_cast<uint32_t *>(frame + Jm.dst_off + (size_t)y * Jm.dst_stride + x0) = o;
+        }
+    }
+}
+
 // The last generations of the pyramid are a few thousand pixels per frame: as k_resample launches they are 3-4 nearly
 // empty grids whose cost is launch + latency chain (C2: 48 us for 6 % of the pixels).  Here ONE workgroup per frame walks
 // those generations in order: a thread produces 4 destination pixels straight from HBM/L2 (own tap evaluation, no LDS
@@ -911,8 +1129,12 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         if (c->dbg_rs_k > 0) K = (uint32_t)std::min(c->dbg_rs_k, std::max(1, c->nframes));  // option rs_k: measurement knob
         const uint32_t ngroups = ((uint32_t)c->nframes + K - 1) / K;
         const dim3 rgrid((c->gen_blocks[g] * ngroups + 7u) & ~7u);
-        hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,
-                           c->gen_blocks[g], ngroups, (uint32_t)c->nframes, K);
+        if (c->rs_bands)
+            hipLaunchKernelGGL(k_resample_bands<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,
+                               c->gen_blocks[g], ngroups, (uint32_t)c->nframes, K);
+        else
+            hipLaunchKernelGGL(k_resample<HT_RS_MAX_PASSES>, rgrid, dim3(256), 0, c->stream, c->d_gen_blocks[g], c->d_arena, c->arena_stride,
+                               c->gen_blocks[g], ngroups, (uint32_t)c->nframes, K);
         HT_HIP(c, hipGetLastError());
         if ((int)g == c->early_gen && c->early_gen > 0) {  // the early scales' planes are complete: their scan starts on the second stream
             ht_status st = ht_launch_scan_early(c, flags);

@@ -299,7 +299,7 @@ struct ht_ctx {
     int dbg_rs_k = 0;  // option rs_k: frames per k_resample workgroup, forced (any value)
     int rs_group = 8;  // k_resample: frames per workgroup at most (option rs_group)
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
-    bool rs_bands = false;  // option rs_bands: the pyramid generations run k_resample_bands (LDS-DMA into wave-private source bands) instead of k_resample
+    bool rs_bands = true;  // option rs_bands=0: the pyramid generations run k_resample (register-staged tile, two barriers per frame) instead of k_resample_bands (A/B)
 
     // frames
     uint8_t *d_frames_own = nullptr;

@@ -794,9 +794,11 @@ __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResa
                 if (f + 1 < f1) {
                     // every LDS read of this frame's band has returned (o[] depends on all of them): the band may be overwritten.  The wait
                     // below is for the DMA alone — this frame's stores are issued behind it, the previous frame's are a pixel phase old.
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    // s_waitcnt through the builtin: the compiler's own counter tracking sees it (behind an inline-asm wait it adds a second
+                    // vmcnt(0) in front of the next frame's first LDS read)
+                    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
                     RSB_DMA(fr, (uint32_t)arena_stride);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
                 }
 #pragma unroll
                 for (int q = 0; q < NP; q++)

@@ -75,6 +75,7 @@ typedef struct ht_config {
                              *   graph_max_frames=N   batches up to N frames replay a captured hipGraph (256; 0 = never)
                              *   split=S, deep_bias=B, deep_v=2|4, deep_grid=N                    tile kernel -> deep kernel hand-off (grid kept >= 16 wavefronts)
                              *   force_exact=1        every integer stage decision re-run on the sequential binary64 path
+                             *   rs_bands=0|1         pyramid generations by k_resample_bands (1: LDS-DMA into wave-private source bands) or k_resample (0)
                              *   early_scan=1, rs_rpt, rs_minwg, rs_k, rs_group, rs_tailtable, rs_tailcap, rs_notail, rs_nofast, rs_nosort, rs_gennames
                              *   host_threads=N       worker threads of the host post-processing (0 = single-threaded)
                              *   force_rccl=1         ht_allgather_* goes through RCCL even with one rank

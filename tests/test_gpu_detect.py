@@ -131,13 +131,14 @@ def test_pyramid_without_tail_kernel(w, h):
         c.close()
 
 
-@pytest.mark.parametrize("opts", ["rs_bands=1", "rs_bands=0", "rs_bands=1,rs_notail=1", "rs_bands=1,rs_nofast=1", "rs_bands=1,rs_rpt=2", "rs_bands=1,rs_k=3"])
+@pytest.mark.parametrize("opts", ["rs_bands=1", "rs_bands=0", "rs_bands=0,rs_notail=1", "rs_bands=0,rs_nofast=1", "rs_bands=0,rs_rpt=2", "rs_bands=0,rs_k=3",
+                                  "rs_bands=1,rs_notail=1", "rs_bands=1,rs_rpt=2", "rs_bands=1,rs_k=3"])
 @pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (38, 30), (641, 363), (1280, 720), (1920, 1080)] + _random_sizes(6, 20260930) + [(1023, 65), (65, 799), (2048, 64)])
 def test_pyramid_both_generation_kernels(w, h, opts):
-    """The pyramid generations are built by k_resample_bands (LDS-DMA into wave-private source bands, no barrier in the frame loop) or
-    by k_resample (register-staged tile, two barriers per frame): the same tile records, the same pixel arithmetic, another thread ->
-    row map.  Forced here on the same inputs, with every generation going through the kernel (rs_notail), the binary64-everywhere mode,
-    smaller tiles and an odd frame group: every plane equals the oracle's."""
+    """The pyramid generations are built by k_resample_bands (the default: LDS-DMA into wave-private source bands, no barrier in the frame
+    loop) or by k_resample (option rs_bands=0: register-staged tile, two barriers per frame): the same tile records, the same pixel
+    arithmetic, another thread -> row map.  Forced here on the same inputs, with every generation going through the kernel (rs_notail),
+    the binary64-everywhere mode, smaller tiles and an odd frame group: every plane equals the oracle's."""
     if "=1," in opts and (w, h) not in [(320, 240), (201, 157), (641, 363), (1280, 720)]:
         pytest.skip("variants of the bands kernel: four geometries")
     c = Context(options=opts)

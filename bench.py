@@ -150,6 +150,39 @@ def sub_records(env, a, prim, t_budget):
     return sub
 
 
+RCCL_INIT_BUDGET_S = 240.0  # communicator creation + first collective; 8 ranks of one node take a few seconds, a 1-rank ncclCommInitAll
+                            # took ~50 s on one test box (tests/test_js_host.py)
+
+
+def init_group(torch, dist, backend, rank, world, local):
+    """init_process_group + the first collective (communicators are created lazily), bounded: a rendezvous or a communicator that does
+    not come up inside RCCL_INIT_BUDGET_S ends the run with a message and a non-zero exit code instead of hanging the driver's N-GPU
+    slot.  Returns the MAX over the ranks of the seconds it took (every rank's line would carry the same figure)."""
+    import datetime
+
+    budget = float(os.environ.get("HT_BENCH_INIT_BUDGET_S", RCCL_INIT_BUDGET_S))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    t_init = time.perf_counter()
+    try:
+        kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=budget), **kw)
+        t = torch.zeros(8, device="cuda" if backend == "nccl" else "cpu")
+        dist.all_reduce(t)
+        if backend == "nccl":
+            torch.cuda.synchronize()
+    except Exception as e:
+        sys.stderr.write(f"bench.py rank {rank}/{world}: {backend} process group did not come up within {budget:.0f} s "
+                         f"({type(e).__name__}: {e})\n")
+        raise SystemExit(3)
+    mine = time.perf_counter() - t_init
+    if mine > budget:
+        sys.stderr.write(f"bench.py rank {rank}/{world}: {backend} init + first collective took {mine:.1f} s (budget {budget:.0f} s)\n")
+        raise SystemExit(3)
+    tm = torch.tensor([mine], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    return round(float(tm.item()), 2)
+
+
 def main():
     a = parse()
     stub = os.environ.get("HT_BENCH_STUB") == "1"
@@ -178,13 +211,11 @@ def main():
     if stub:
         from benchlib.launch import stub_bench
 
-        if world > 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        init_s = init_group(torch, dist, "gloo", rank, world, local) if world > 1 else None
         prim = stub_bench(Env(torch, dist, rank, world, local, stub=True), a)
         if rank == 0:
             line = bl.compose("STUB — launcher / collective plumbing only, not a measurement", prim, {}, world,
-                              dict(backend="gloo"))
+                              dict(backend="gloo", rccl_init_s=init_s))
             line["data"] = "stub"
             bl.emit(line, prim, line_out, write_sub=False)
         if world > 1:
@@ -197,13 +228,7 @@ def main():
     torch.cuda.set_device(local)
     rccl_init_s = None
     if world > 1 or (launched and "MASTER_PORT" in os.environ):  # under a launcher even ONE rank gets its RCCL group
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        t_init = time.perf_counter()
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        t = torch.zeros(8, device="cuda")
-        dist.all_reduce(t)  # communicators are created lazily: the first collective pays for them
-        torch.cuda.synchronize()
-        rccl_init_s = round(time.perf_counter() - t_init, 2)
+        rccl_init_s = init_group(torch, dist, "nccl", rank, world, local)
     env = Env(torch, dist, rank, world, local)
     t_run = time.perf_counter()
     gather = True if (world == 1 and dist.is_initialized()) else None

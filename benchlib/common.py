@@ -120,16 +120,22 @@ def device_copy_ceiling(torch):
     return gbs
 
 
-def load_pmc(workload):
+def load_pmc(workload, lib=None, path=None):
     """profiles/traffic.json — the committed rocprofv3 counter passes (tools/collect_profiles.py), per detect STEP:
     `per_step` = HBM bytes per bench timer name (every launch's own FETCH_SIZE / WRITE_SIZE summed; `resample` = the
-    k_resample launches + k_resample_tail), `valu_per_step` = SQ_INSTS_VALU wave instructions of all kernels."""
+    pyramid generation launches + the tail kernel), `valu_per_step` = SQ_INSTS_VALU wave instructions of all kernels.
+    The file records the fingerprint of the code objects it was measured on (`_build`, benchlib/fingerprint.py); the
+    third return value lists the translation units of `workload` whose code in the library being timed NOW differs from
+    that build ([] = the counters belong to this build; None = the file carries no fingerprint: treated as stale)."""
+    from .fingerprint import stale_units
+
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            j = json.load(fh).get(workload, {})
-        return j.get("per_step", {}), j.get("valu_per_step")
+        with open(path or os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            doc = json.load(fh)
+        j = doc.get(workload, {})
+        return j.get("per_step", {}), j.get("valu_per_step"), stale_units(doc.get("_build"), workload, lib)
     except Exception:
-        return {}, None
+        return {}, None, None
 
 
 def free_port():

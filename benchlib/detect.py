@@ -146,9 +146,16 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
     roofline = dominant_roofline(per_step, {k: v["launches"] / psteps for k, v in kt.items()}, b_detect * nf,
                                  dict(algorithmic_bytes_per_frame=b_detect, frames_per_step=nf))
     # PMC figures per step come from the committed rocprofv3 counter passes — only for the shape they were taken at
-    traffic, valu = load_pmc(name) if (nf, scaling) == (nf_default, "weak") else ({}, None)
+    traffic, valu, stale = load_pmc(name) if (nf, scaling) == (nf_default, "weak") else ({}, None, [])
+    # the counters are constants of the build they were measured on: if the library being timed is another build they stay in the
+    # record as what they are (`traffic_stale`) and the figure derived from them for THIS run (valu_issue) is dropped
+    traffic_stale = bool(traffic) and (stale is None or len(stale) > 0)
     roofline["traffic"] = traffic.get(roofline["kernel"])
     roofline["traffic_source"] = TRAFFIC_SOURCE if roofline["traffic"] else None
+    if traffic_stale:
+        roofline["traffic_stale"] = True
+        roofline["traffic_source"] = TRAFFIC_SOURCE + " — STALE: measured on another build of " + (", ".join(stale) if stale else "the library (no fingerprint recorded)")
+        valu = None
     for k in roofline["co_dominant"]:
         roofline["co_dominant"][k]["traffic"] = traffic.get(k)
     dev_ms = sum(per_step.values())
@@ -175,6 +182,7 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
         for k in own if k in per_step}
     if traffic:
         rec["path_traffic_over_algorithmic"] = round(sum(v for v in traffic.values() if v) / (b_detect * nf), 3)
+        rec["traffic_stale"] = traffic_stale
     rec["device_ms_per_step"] = round(dev_ms, 5)
     # whole-path figures (every kernel of a step): device time, and the wall clock of the timed region
     rec["path_hbm_gbs"] = round(b_detect * nf / (dev_ms * 1e-3) / 1e9, 2)
@@ -194,9 +202,11 @@ def detect_bench(env, a, name, steps, warmup, scaling="weak", frames_per_gpu=0, 
         sc = ctx.stage_counts()
         per_stage = [int(v) for v in ctx.cascade.stages["count"]]
         feat_evals = sum(int(sc[j]) * per_stage[j] for j in range(len(per_stage)))
-        rec.update(feature_evals_per_s=round(feat_evals / (dev_ms * 1e-3), 1),
+        rec.update(feature_evals_per_s_device=round(feat_evals / (dev_ms * 1e-3), 1),
                    windows_per_frame=int(ctx.windows_per_frame),
-                   windows_per_s=round(float(sc[0]) / (dev_ms * 1e-3), 1), stage_in=[int(v) for v in sc])
+                   windows_per_s_device=round(float(sc[0]) / (dev_ms * 1e-3), 1),  # over the summed device time of the profiling pass
+                   windows_per_s=round(float(sc[0]) / (wall_ms * 1e-3), 1),  # over the timed region's wall clock
+                   stage_in=[int(v) for v in sc])
     if extras:
         rec["depth1"] = depth1_block(ctx, finish, a.flags, nf, wall_ms)
         rec["pcie_inclusive"] = pcie_block(env, ctx, base, idx.cpu().numpy(), nf, W, H, finish, a.flags)

@@ -22,6 +22,9 @@ def compact_roofline(r):
             "kernel_ms_per_step")
     out = {k: r.get(k) for k in keep}
     out["traffic_source"] = "profiles/traffic.json (PMC pass, not this run)" if r.get("traffic") else None
+    if r.get("traffic_stale"):
+        out["traffic_stale"] = True
+        out["traffic_source"] = "profiles/traffic.json (PMC pass of ANOTHER build: stale)"
     co = r.get("co_dominant") or {}
     if co:
         out["co_dominant"] = {k: v["frac"] for k, v in co.items()}
@@ -73,6 +76,7 @@ def compose(metric, prim, sub, world, extra=None):
         "cpu_port_all_cores": get(prim, "cpu_baseline_port", "all_cores", "cores"),
         "path_hbm_frac": prim.get("path_hbm_frac"), "wall_hbm_frac": prim.get("wall_hbm_frac"),
         "valu_issue_frac": get(prim, "valu_issue", "frac_wall"),
+        "traffic_stale": prim.get("traffic_stale") or None,  # only when true: the PMC constants belong to another build (valu_issue_frac is then absent)
         "device_ms_per_step": prim.get("device_ms_per_step"),
         "depth1_ms_per_step": get(prim, "depth1", "ms_per_step"),
         "pcie_inclusive_value": get(prim, "pcie_inclusive", "value"),
@@ -89,6 +93,7 @@ def compose(metric, prim, sub, world, extra=None):
             "roofline_frac_720p": get(c4, "roofline", "frac"), "roofline_kernel_720p": get(c4, "roofline", "kernel"),
             "path_hbm_frac_720p": c4.get("path_hbm_frac"), "wall_hbm_frac_720p": c4.get("wall_hbm_frac"),
             "valu_issue_frac_720p": get(c4, "valu_issue", "frac_wall"),
+            "traffic_stale_720p": c4.get("traffic_stale") or None,
             "depth1_ms_per_step_720p": get(c4, "depth1", "ms_per_step"),
             "pcie_inclusive_value_720p": get(c4, "pcie_inclusive", "value"),
             "cpu_baseline_720p": get(c4, "cpu_baseline", "value"),

@@ -290,9 +290,16 @@ class Context:
         self._check(self._lib.ht_profile(self._h, int(on)))
 
     def kernel_times(self, reset: bool = True) -> dict:
-        buf = np.zeros(32, dtype=native.KERNEL_TIME_DTYPE)
-        n = C.c_int32(32)
+        # the entry count first (no buffer, nothing reset), then a buffer that holds them all: with a fixed 32 entries the pseudo-timers
+        # the library appends behind the real ones (cs_fused_launches_*) fell off the end once many timers existed
+        n = C.c_int32(0)
+        self._check(self._lib.ht_kernel_times(self._h, None, C.byref(n), 0))
+        cap = max(int(n.value), 1)
+        buf = np.zeros(cap, dtype=native.KERNEL_TIME_DTYPE)
+        n = C.c_int32(cap)
         self._check(self._lib.ht_kernel_times(self._h, buf.ctypes.data, C.byref(n), int(reset)))
+        if n.value > cap:
+            raise RuntimeError(f"ht_kernel_times: {n.value} entries for a buffer of {cap}")
         return {b["name"].decode(): dict(ms=float(b["ms"]), launches=int(b["launches"])) for b in buf[: n.value]}
 
     @property

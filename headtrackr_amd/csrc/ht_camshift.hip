@@ -981,6 +981,16 @@ void ht_cluster_gate_forget(const ht_ctx *c) {
         it->second.multi = false;
     }
 }
+// ht_detect_enqueue around its graph capture.  Setting the flag takes the gate's lock, and fused_threads() holds that lock across its
+// queries: a query of this context's stream either completed before the capture began or sees the flag and is skipped.
+void ht_capture_mark(ht_ctx *c, bool on) {
+    if (on) {
+        std::lock_guard<std::mutex> lk(cluster_gate().mu);
+        c->capturing.store(true);
+    } else {
+        c->capturing.store(false);
+    }
+}
 namespace {
 // fetched with every result read-back: a cluster barrier that ran out of its cycle budget surfaces as a status code
 ht_status cs_check_err(ht_ctx *c, const char *where) {
@@ -1124,11 +1134,15 @@ static int fused_threads(ht_ctx *c, int n) {
         std::lock_guard<std::mutex> lk(gate.mu);  // ht_destroy forgets a context under this lock before it destroys its stream
         auto &fu = gate.dev[c->device].fused;
         if (std::find(fu.begin(), fu.end(), c) == fu.end()) fu.push_back(c);
-        for (const ht_ctx *o : fu)
-            if (o != c && o->stream && hipStreamQuery(o->stream) == hipErrorNotReady) {
+        for (const ht_ctx *o : fu) {
+            if (o == c || !o->stream) continue;
+            // a context that is capturing its detect sequence is about to have work in flight; its stream must not be queried
+            // (hipErrorStreamCaptureUnsupported, and the capture may be invalidated: ADVICE round 5)
+            if (o->capturing.load() || hipStreamQuery(o->stream) == hipErrorNotReady) {
                 other_busy = true;
                 break;
             }
+        }
         (void)hipGetLastError();  // hipErrorNotReady is an answer, not an error: keep it out of the launch checks that follow
     }
     return (n > c->num_cus || other_busy) ? FUSED_NT_SMALL : FUSED_NT;

@@ -47,6 +47,7 @@ HtRange::~HtRange() {
 }
 
 // every live context of the process: ht_device_free looks for OTHER contexts that still have frames bound inside the buffer
+#include <atomic>
 #include <mutex>
 static std::mutex g_live_mu;
 static std::vector<ht_ctx *> g_live;
@@ -60,6 +61,7 @@ struct HtOrphan {
     bool orphan;  // false: released by its own context's ht_destroy
 };
 static std::vector<HtOrphan> g_orphans;
+static std::atomic<int> g_orphan_count{0};  // g_orphans.size(), readable without the lock: the frame-binding calls look at it first
 
 // g_live_mu held.  Reads the other contexts' d_frames without their lock: a context being re-bound concurrently with the destruction
 // or ht_device_free of the buffer it is bound to is a caller error (include/headtrackr_hip.h, "Lifetime of shared frame buffers").
@@ -68,6 +70,32 @@ static bool bound_by_live_context(const ht_ctx *except, int device, const void *
     for (const ht_ctx *o : g_live)
         if (o != except && o->device == device && o->d_frames && o->d_frames >= pb && o->d_frames < pb + bytes) return true;
     return false;
+}
+
+// A context's frames moved (bind / upload / swap / free): orphans that no live context is bound inside any more are released here as
+// well, not only by some later ht_destroy — a host that re-binds its last binder elsewhere and never destroys anything would keep
+// the HBM for the life of the process.  One relaxed load when there are no orphans (the streaming hosts bind per step).
+static void sweep_orphans(ht_ctx *c) {
+    if (g_orphan_count.load(std::memory_order_relaxed) == 0) return;
+    std::vector<HtOrphan> release;
+    {
+        std::lock_guard<std::mutex> lk(g_live_mu);
+        for (size_t i = 0; i < g_orphans.size();) {
+            if (!bound_by_live_context(nullptr, g_orphans[i].device, g_orphans[i].p, g_orphans[i].bytes)) {
+                release.push_back(g_orphans[i]);
+                g_orphans.erase(g_orphans.begin() + (long)i);
+            } else {
+                i++;
+            }
+        }
+        g_orphan_count.store((int)g_orphans.size(), std::memory_order_relaxed);
+    }
+    for (auto &a : release) {  // whatever the context that just moved away (or anybody else) still had enqueued against it has to be through
+        (void)hipSetDevice(a.device);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(a.p);
+    }
+    if (!release.empty() && c) (void)hipSetDevice(c->device);
 }
 
 static inline HtPostCfg post_cfg(const ht_ctx *c) { return HtPostCfg{c->interval, c->cw, c->ch}; }
@@ -280,7 +308,7 @@ static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) 
         const int iv = (int)std::max<long long>(std::min<long long>(v, 1ll << 30), -(1ll << 30));
         if (key == "rs_rpt") { if (iv >= 1 && iv <= HT_RS_MAX_PASSES) c->rs_rpt = iv; }
         else if (key == "rs_tailtable") c->tail_table = iv < 0 ? 0 : (iv > 2 ? 2 : (int)iv), c->tail_table_forced = true;
-        else if (key == "rs_tailcap") c->rs_tailcap = (uint64_t)std::max<long long>(v, 0);
+        else if (key == "rs_tailcap") c->rs_tailcap = (uint64_t)std::max<long long>(v, 0), c->rs_tailcap_forced = true;
         else if (key == "rs_notail") c->rs_notail = iv != 0;
         else if (key == "rs_nofast") c->rs_nofast = iv != 0;
         else if (key == "rs_nosort") c->rs_nosort = iv != 0;
@@ -288,7 +316,7 @@ static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) 
         else if (key == "rs_gennames") c->rs_gennames = iv != 0;
         else if (key == "rs_minwg") c->rs_min_wgs = std::max(1, iv);
         else if (key == "rs_k") c->dbg_rs_k = iv;
-        else if (key == "rs_group") { if (iv >= 1 && iv <= 64) c->rs_group = iv; }
+        else if (key == "rs_group") { if (iv >= 1 && iv <= 64) c->rs_group = iv, c->rs_group_forced = true; }
         else if (key == "early_scan") c->early_scan = iv != 0;
         else if (key == "force_exact") c->dbg_force_exact = iv;
         else if (key == "deep_bias") c->deep_bias = (uint32_t)std::max(0, iv);
@@ -452,6 +480,7 @@ extern "C" void ht_destroy(ht_ctx *c) {
                 i++;
             }
         }
+        g_orphan_count.store((int)g_orphans.size(), std::memory_order_relaxed);
     }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -684,12 +713,19 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
     // tail plan: from the first generation g0 on which every generation has <= HT_TAIL_MAX_JOBS jobs and all of them
     // together <= tail_cap destination pixels per frame, one workgroup per frame does the rest of the pyramid in one launch
     // (k_resample_tail) instead of one nearly empty launch per generation.
-    const uint64_t tail_cap = c->rs_tailcap;
+    // Small batches (a live feed's frame, the 8 feeds of a streaming step) are latency chains, not throughput: the tail kernel is ONE
+    // workgroup per frame walking its generations behind barriers — 21 us for 17 k pixels of a single 320x240 frame, the longest kernel
+    // of the call —, while a k_resample_bands launch of the same generation is 4.5 us on the otherwise idle chip.  rocprofv3 kernel
+    // trace of single-frame calls (tools/gpu_one_frame_trace.sh, round 6): cap 32 768 -> 4 000 pixels takes 74.1 -> 63.5 us off the
+    // device span at 320x240 (generation 4 as a launch, generations 5 - 7 in the tail) and 92.9 -> 79.3 us at 1920x1080 (no tail at all);
+    // batches that fill the chip keep the large cap (C2: cap 4 000 costs +3 % on the pyramid, no tail at all +19 %).
+    const uint64_t tail_cap = c->rs_tailcap_forced ? c->rs_tailcap : (max_batch <= 16 ? 4000u : c->rs_tailcap);
     // which tail kernel: measured (3 batches in flight), the table-driven binary32 tail (68 VGPRs, 35 KB LDS) is worth +4-5 % at
     // 128 x 720p but costs 3 % at 256 x 320x240, where its grid puts a 1024-thread workgroup on EVERY CU and its footprint keeps
     // the other batches' kernels from sharing them; the round-1 binary64 tail (41 VGPRs) is kept for batches that cover the chip.
     // Larger caps (generation 3 of C2 = 54 k pixels in the tail) lose with either kernel.
-    if (!c->tail_table_forced) c->tail_table = max_batch <= 128 ? 1 : 0;
+    // ... and for a handful of frames: 7.6 us against the table form's 10.3 for generations 5 - 7 of a single 320x240 frame (the same trace)
+    if (!c->tail_table_forced) c->tail_table = (max_batch <= 128 && max_batch > 16) ? 1 : 0;
     c->tail_first_gen = 0;
     if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
     if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;
@@ -861,6 +897,7 @@ extern "C" ht_status ht_upload_frames(ht_ctx *c, const uint8_t *host_rgba, int32
     c->d_frames = c->d_frames_own;
     c->frame_stride = fbytes;
     c->nframes = n;
+    sweep_orphans(c);
     return HT_OK;
 }
 
@@ -909,6 +946,7 @@ extern "C" ht_status ht_swap_frames(ht_ctx *c) {
     c->frame_stride = (size_t)c->W * c->H * 4;
     c->nframes = c->back_n;
     c->back_n = 0;
+    sweep_orphans(c);
     return HT_OK;
 }
 
@@ -921,6 +959,7 @@ extern "C" ht_status ht_bind_frames_device(ht_ctx *c, const void *dev_rgba, int3
     c->d_frames = (const uint8_t *)dev_rgba;
     c->frame_stride = frame_stride;
     c->nframes = n;
+    sweep_orphans(c);
     return HT_OK;
 }
 
@@ -970,6 +1009,7 @@ extern "C" ht_status ht_device_free(ht_ctx *c, void *p) {
     }
     c->user_allocs.erase(it);
     HT_HIP(c, hipFree(p));
+    sweep_orphans(c);
     return HT_OK;
 }
 extern "C" ht_status ht_device_upload(ht_ctx *c, void *dst_dev, const void *src_host, size_t bytes) {
@@ -1070,10 +1110,12 @@ extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
             g->frames = c->d_frames, g->frame_stride = c->frame_stride, g->nframes = c->nframes, g->flags = flags;
         }
         if (!g->exec && g->seen == 1) {
+            ht_capture_mark(c, true);
             if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 st = detect_enqueue_body(c, flags);
                 hipGraph_t graph = nullptr;
                 const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+                ht_capture_mark(c, false);
                 if (st == HT_OK && e == hipSuccess && graph && hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                     g->graph = graph;
                 } else {  // not capturable here: keep launching plainly
@@ -1083,6 +1125,7 @@ extern "C" ht_status ht_detect_enqueue(ht_ctx *c, uint32_t flags) {
                     (void)hipGetLastError();
                 }
             } else {
+                ht_capture_mark(c, false);
                 (void)hipGetLastError();
                 g->seen = 1 << 30;
             }

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -168,15 +169,19 @@ struct alignas(64) HtTileRec {
 };
 static_assert(sizeof(HtTileRec) == 64, "HtTileRec");
 
-// Survivor handed from the tile kernel to the deep kernel.
-struct HtQueueEntry {
+// Survivor handed from the tile kernel to the deep kernel.  The tile kernel holds the scale's plane offsets and strides in scalar
+// registers (its tile record), so the entry carries the window's three plane origins ready-made: the deep kernel used to look the
+// scale's three level records up behind the entry — a third dependent memory round trip in front of every window's patch load.
+struct alignas(16) HtQueueEntry {
     uint32_t frame;
     uint16_t x, y;
     uint8_t scale, q;
+    uint16_t stage;        // first stage the deep kernel has to run
+    uint32_t o0, o1, o2;   // byte offsets of the window origin inside the frame's arena: level i (ccv.js:180,235), i + 6 (236), variant q of i + 12 (237)
+    uint16_t s0, s1, s2;   // row strides of the three planes
     uint16_t pad;
-    uint32_t pad2;
 };
-static_assert(sizeof(HtQueueEntry) == 16, "HtQueueEntry");
+static_assert(sizeof(HtQueueEntry) == 32, "HtQueueEntry");
 
 // k_scan_deep_lds hands its queue entries out through HT_DEEP_CTRS counters, one per 256-byte line, in the 4 KB behind the queue's
 // last entry (zeroed by the first workgroup of every k_scan_tiles launch): same-address atomics retire at ~90 per us, one counter for
@@ -291,13 +296,17 @@ struct ht_ctx {
     int tail_table = 1;  // k_resample_tail with host tap tables: 1 = compact taps in LDS, 2 = taps from L2 / small footprint; 0: the round-1 binary64 tail (option rs_tailtable)
     bool tail_table_forced = false;  // option rs_tailtable given: ht_set_geometry keeps it instead of choosing by batch size
     bool rs_nofast = false, rs_nosort = false, rs_notail = false, rs_gennames = false;  // options of the same names (A/B, cross-checks)
-    uint64_t rs_tailcap = 32768;     // destination pixels per frame the tail kernel takes at most (option rs_tailcap)
+    uint64_t rs_tailcap = 32768;     // destination pixels per frame the tail kernel takes at most (option rs_tailcap; batches <= 16 frames: 4 000 unless the option is given)
+    bool rs_tailcap_forced = false;
     int rs_maxgen = 1 << 30;         // HT_DEBUG_KNOBS builds only (results stale): pyramid generations built
     bool force_rccl = false;         // option force_rccl: ht_allgather_* runs RCCL even with one rank
     int host_threads = -1;           // option host_threads: workers of the host post-processing (-1 = auto, 0 = none)
     int rs_min_wgs = 1536;  // ... but never fewer workgroups per launch than this (option rs_minwg; round 4, three batches in flight at C2: 1024 / 1536 / 2048 / 4096 -> 0.2288 / 0.2283 / 0.2303 / 0.2365 ms per step)
     int dbg_rs_k = 0;  // option rs_k: frames per k_resample workgroup, forced (any value)
-    int rs_group = 8;  // k_resample: frames per workgroup at most (option rs_group)
+    int rs_group = 8;  // pyramid generation kernels: frames per workgroup at most (option rs_group).  Frames of >= 400 k pixels take 4 unless the option is
+                       // given: with k_resample_bands at 128 x 720p, K = 8 / 4 / 3 / 2 / 1 -> resample 0.480 / 0.456 / 0.455 / 0.465 / 0.529 ms per step,
+                       // wall (two in flight) 1.1114 / 1.1040 / 1.1103 / 1.1295 / 1.2585; at 256 x 320x240 8 stays best (wall 0.2184 vs 0.2218)
+    bool rs_group_forced = false;
     int rs_rpt = 4;  // k_resample: destination rows per thread (tile = 64 x 16*rs_rpt)
     bool rs_bands = true;  // option rs_bands=0: the pyramid generations run k_resample (register-staged tile, two barriers per frame) instead of k_resample_bands (A/B)
 
@@ -314,6 +323,9 @@ struct ht_ctx {
     int nframes = 0;
     // small batches (a live feed = 1 frame) are launch-bound: ~10 dependent launches cost more than their kernels.  Their sequence is
     // captured into a hipGraph per (frames pointer, count, flags) and replayed.  0 disables (option graph_max_frames)
+    // set (under the cluster gate's lock: ht_capture_mark) while this context's stream is between hipStreamBeginCapture and EndCapture:
+    // another context's fused_threads() must not hipStreamQuery a capturing stream (the query fails and may invalidate the capture)
+    std::atomic<bool> capturing{false};
     int graph_max_frames = 256;  // round 4: replaying a 256-frame C2 batch instead of launching its 9 kernels: 0.2253 -> 0.2239 ms per step at three in flight (16 until then: only launch-bound small batches)
     std::vector<HtDetectGraph> graphs;
     uint64_t graph_launches = 0;  // measurement: enqueues served by a graph replay
@@ -444,6 +456,7 @@ struct HtProfScope {
 
 // implemented in the .hip files ---------------------------------------------------------------------------
 void ht_cluster_gate_forget(const ht_ctx *ctx);             // ht_camshift.hip
+void ht_capture_mark(ht_ctx *ctx, bool on);                 // ht_camshift.hip: ctx->capturing, ordered against fused_threads' stream queries
 ht_status ht_launch_pyramid(ht_ctx *ctx, uint32_t flags);   // ht_pyramid.hip
 ht_status ht_launch_scan(ht_ctx *ctx, uint32_t flags);      // ht_scan.hip
 ht_status ht_launch_scan_early(ht_ctx *ctx, uint32_t flags); // ht_scan.hip: called by ht_launch_pyramid after generation early_gen

@@ -1125,7 +1125,8 @@ ht_status ht_launch_pyramid(ht_ctx *c, uint32_t flags) {
         // frames per workgroup: as many as keep >= ~4 workgroups per CU slot in the launch, at most rs_group; groups never
         // straddle the 8 XCD shares of the batch when the batch is a multiple of 8 * K
         uint32_t K = 1;
-        while (K * 2 <= (uint32_t)c->rs_group && (uint64_t)c->gen_blocks[g] * ((uint32_t)c->nframes / (K * 2)) >= (uint64_t)c->rs_min_wgs &&
+        const uint32_t kmax = (uint32_t)((!c->rs_group_forced && (int64_t)c->W * c->H >= 400000) ? std::min(c->rs_group, 4) : c->rs_group);
+        while (K * 2 <= kmax && (uint64_t)c->gen_blocks[g] * ((uint32_t)c->nframes / (K * 2)) >= (uint64_t)c->rs_min_wgs &&
                (uint32_t)c->nframes % (K * 2 * 8) == 0)
             K *= 2;
         if (c->dbg_rs_k > 0) K = (uint32_t)std::min(c->dbg_rs_k, std::max(1, c->nframes));  // option rs_k: measurement knob

@@ -562,19 +562,30 @@ __global__ __launch_bounds__(NT, HT_TILE_WPS) void k_scan_tiles(const uint8_t *_
             const uint32_t qb = s_qbase;
             const uint32_t room = qb < queue_cap ? queue_cap - qb : 0u;
             const uint32_t npush = min(n_in, room);
+            // the plane offsets / strides for the entries: the tile record is read AGAIN here (one scalar load, only tiles with survivors get
+            // this far) — kept alive from the staging code they cost 11 scalar registers spilled across the whole cascade
+            uint32_t lt2 = lt;
+            asm volatile("" : "+s"(lt2));
+            const HtTileRec Rq = tile_recs[lt2];
+            const uint32_t q_s0 = Rq.sh0 & 0xffffu, q_s1 = Rq.sh1 & 0xffffu, q_s2 = Rq.sh2 & 0xffffu;
             for (uint32_t i = tid; i < npush; i += NT) {
                 const uint32_t id = QB(0, qoff + i);
                 const uint32_t yy = __umul24(id, S.div_magic) >> 20, xx = id - __umul24(yy, (uint32_t)S.tw2);
                 const uint32_t ax = (uint32_t)X0 + xx, ay = (uint32_t)Y0 + yy;
-                HtQueueEntry e;
-                e.frame = frame;
-                e.x = (uint16_t)(ax >> 1);
-                e.y = (uint16_t)(ay >> 1);
-                e.scale = (uint8_t)S.l0;
-                e.q = (uint8_t)(((ay & 1u) << 1) | (ax & 1u));
-                e.pad = (uint16_t)s;  // first stage the deep kernel has to run
-                e.pad2 = 0;
-                queue[qb + i] = e;
+                // (built as two 16-byte words: as a struct with 1-, 2- and 4-byte members the entry went through scratch memory)
+                const uint32_t q = ((ay & 1u) << 1) | (ax & 1u);
+                uint4 w0, w1;
+                w0.x = frame;
+                w0.y = (ax >> 1) | (ay >> 1) << 16;                        // x, y
+                w0.z = S.l0 | q << 8 | (uint32_t)s << 16;                  // scale, q, first stage the deep kernel has to run
+                // window origins on the three planes (HT_WIN_SETUP's expressions with 4y + 2dy = 2 ay, 2y + dy = ay)
+                w0.w = Rq.off0 + 2u * ay * q_s0 + 2u * ax;  // o0
+                w1.x = Rq.off1 + ay * q_s1 + ax;            // o1
+                w1.y = (q == 0 ? Rq.off2[0] : (q == 1 ? Rq.off2[1] : (q == 2 ? Rq.off2[2] : Rq.off2[3]))) + (ay >> 1) * q_s2 + (ax >> 1);  // o2
+                w1.z = q_s0 | q_s1 << 16;                   // s0, s1
+                w1.w = q_s2;                                // s2, pad
+                uint4 *qe = reinterpret_cast<uint4 *>(queue + qb + i);
+                qe[0] = w0, qe[1] = w1;
             }
             TL_STAMP(10);
             if (npush == n_in) return;  // the common case
@@ -779,9 +790,10 @@ __global__ __launch_bounds__(64 * DEEP_WAVES) void k_scan_deep(const uint8_t *__
     const uint32_t n = min(ctr->nqueue, queue_cap);
     for (uint32_t e = wave; e < n; e += nwaves) {
         const HtQueueEntry ent = queue[e];
-        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
-                     (uint32_t)ent.y)
-        int j = (int)ent.pad;  // first stage to run here
+        const uint8_t *fb = arena + (uint64_t)ent.frame * arena_stride;
+        const uint32_t o0 = ent.o0, o1 = ent.o1, o2 = ent.o2;
+        const int s0 = ent.s0, s1 = ent.s1, s2 = ent.s2;
+        int j = (int)ent.stage;  // first stage to run here
         HtDevStage st = stages[j];
         // first feature chunk and the window patch are fetched together (one memory latency)
         PatchFeatRegs cur;
@@ -927,6 +939,27 @@ __device__ __forceinline__ long long wave_sum_i64_dpp(long long v) {
     return l0 + (l1 << 21) + (l2 << 42) - (64ll << 40);
 }
 
+// A queue entry through the SCALAR cache: the index is wave-uniform, but the kernel contains memory clobbers (the hand-written atomic), so the
+// compiler does not prove the load "noclobber" and fetches the entry with vector loads into 8 VGPRs — which then live across the stage
+// passes next to the prefetched next entry, and at this register budget the patch gathers were issued one by one, each waited for on the
+// spot.  Read through the constant address space the entry is two s_load_dwordx4 into scalar registers.  (The tile kernel wrote the queue
+// in an earlier launch: nothing in this kernel stores to it.)
+struct DeepEntry {
+    uint32_t frame, x, y, scale, q, stage, o0, o1, o2, s0, s1, s2;
+};
+__device__ __forceinline__ DeepEntry deep_entry(const HtQueueEntry *__restrict__ queue, uint32_t e) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) u32x4 *cptr4;
+    cptr4 p = (cptr4)(reinterpret_cast<uintptr_t>(queue) + (uintptr_t)e * sizeof(HtQueueEntry));
+    const u32x4 w0 = p[0], w1 = p[1];
+    DeepEntry d;
+    d.frame = w0.x, d.x = w0.y & 0xffffu, d.y = w0.y >> 16;
+    d.scale = w0.z & 0xffu, d.q = (w0.z >> 8) & 0xffu, d.stage = w0.z >> 16;
+    d.o0 = w0.w, d.o1 = w1.x, d.o2 = w1.y;
+    d.s0 = w1.z & 0xffffu, d.s1 = w1.z >> 16, d.s2 = w1.w & 0xffffu;
+    return d;
+}
+
 #ifdef HT_DEEP_TIMELINE  // tools/gpu_deep_timeline.py: shader-clock stamps per wavefront of k_scan_deep_lds (first window of each wavefront)
 __device__ unsigned long long g_deep_tl[8192][8];  // entry, table copied, patch loaded, window done, last stage run, exact-sum start
 #define DL_STAMP(i)                                                                                                  \
@@ -956,15 +989,20 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
     bool dl_first = true;
 #endif
     DL_STAMP(0);
+    const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the patch address, the queue index and the statistics row become scalar registers
+    const uint32_t wave = blockIdx.x * DEEPL_WAVES + wv, nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * DEEPL_WAVES));
+    // The memory round trips in front of a window's first stage used to be five, one behind the other: queue count -> table copy ->
+    // queue entry -> the scale's level records -> patch gathers (tools/gpu_deep_timeline.py: table copy 5 k + patch load 5.5 k cycles).
+    // Now the wavefront's first entry is requested before the table copy (it needs nothing from it), entries carry their plane origins,
+    // and every further entry is requested as soon as its index is known, a whole window ahead: one round trip (the gathers) per window.
+    DeepEntry ent = deep_entry(queue, min(wave, n - 1u));
     for (uint32_t i = threadIdx.x; i < packed_count * 2u; i += blockDim.x) tab[i] = reinterpret_cast<const uint4 *>(packed)[i];
     for (uint32_t i = threadIdx.x; i < (uint32_t)nstages * (sizeof(HtDevStage) / 16); i += blockDim.x)
         reinterpret_cast<uint4 *>(s_stages)[i] = reinterpret_cast<const uint4 *>(stages)[i];
     __syncthreads();
     DL_STAMP(1);
-    const uint32_t lane = threadIdx.x & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: the patch address, the queue index and the statistics row become scalar registers
     uint8_t *patch = per_wave + wv * (PATCH_BYTES + 512);
     double *sel_buf = reinterpret_cast<double *>(patch + PATCH_BYTES);
-    const uint32_t wave = blockIdx.x * DEEPL_WAVES + wv, nwaves = (uint32_t)__builtin_amdgcn_readfirstlane((int)(gridDim.x * DEEPL_WAVES));
     unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
     // Queue entries are handed out dynamically: a wavefront's first window is entry `wave`, every further one comes from a counter.
     // A window that survives all 16 stages costs ~43 k cycles, one that dies in the stage it was handed over at ~6 k, and a C2 batch
@@ -988,11 +1026,13 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
             // code object of every build (the register is written by the atomic and first read after that s_waitcnt).
             asm volatile("global_atomic_add %0, %1, %2, %3 sc0" : "=v"(nxt) : "v"(zero), "v"(one), "s"(my_ctr) : "memory");
         }
-        const HtQueueEntry ent = queue[e];
         uint32_t ln = lane;  // the gathers' index arithmetic from an opaque lane number: as loop invariants it would be hoisted out of the window
         asm volatile("" : "+v"(ln));  // loop and held (spilled, at this budget) across the stage passes
-        HT_WIN_SETUP(arena + (uint64_t)ent.frame * arena_stride, levels, next, (uint32_t)ent.scale, (uint32_t)ent.q, (uint32_t)ent.x,
-                     (uint32_t)ent.y)
+        const uint8_t *fb = arena + (uint64_t)ent.frame * arena_stride;
+        const uint32_t o0 = ent.o0, o1 = ent.o1, o2 = ent.o2;
+        const int s0 = (int)ent.s0, s1 = (int)ent.s1, s2 = (int)ent.s2;
+        const DeepEntry cur = ent;  // this window (frame, x, y, scale, q, first stage); `ent` becomes the next one below
+        uint32_t e_next = n;
         {
             uint32_t pa[5], pb[3], pc = 0;
 #pragma unroll
@@ -1025,17 +1065,21 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
             // the next entry's index has arrived with the gathers (issued before them): parked in the patch's spare bytes, not in a
             // register that would live across the stage passes (at 80 VGPRs that one register was 9 spills)
             static_assert(PATCH2 + 36 <= 760 && PATCH_BYTES >= 764, "spare bytes of the patch");
-            if (HT_DEEP_DYNAMIC && lane == 0) {
-                asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt) : : "memory");  // the gathers before it in the queue have been consumed above
-                *reinterpret_cast<uint32_t *>(&patch[760]) = nxt;
+            if (HT_DEEP_DYNAMIC) {
+                if (lane == 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(nxt) : : "memory");  // the gathers before it in the queue have been consumed above
+                // the k-th entry handed out by counter c is nwaves + HT_DEEP_CTRS * k + c; requested now, it arrives during the stage passes
+                e_next = nwaves + HT_DEEP_CTRS * (uint32_t)__builtin_amdgcn_readlane((int)nxt, 0) + (wave & (HT_DEEP_CTRS - 1u));
+            } else {
+                e_next = e + nwaves;
             }
+            if (e_next < n) ent = deep_entry(queue, e_next);  // two scalar loads (wave-uniform index), in flight during the stage passes
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         DL_STAMP(2);
         bool alive = true;
         double conf = 0.0;
-        for (int j = (int)ent.pad; j < nstages; j++) {
+        for (int j = (int)cur.stage; j < nstages; j++) {
             const HtDevStage st = s_stages[j];
             const uint32_t base = st.first - packed_first;  // index of the stage's first record in the LDS table
             if (lane == 0 && my_stats) atomicAdd(&my_stats[j], 1ull);
@@ -1130,11 +1174,11 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
             const uint32_t pos = atomicAdd(&ctr->nhits, 1u);
             if (pos < hit_cap) {
                 ht_hit h;
-                h.frame = ent.frame;
-                h.x = ent.x;
-                h.y = ent.y;
-                h.scale = ent.scale;
-                h.q = ent.q;
+                h.frame = cur.frame;
+                h.x = (uint16_t)cur.x;
+                h.y = (uint16_t)cur.y;
+                h.scale = (uint8_t)cur.scale;
+                h.q = (uint8_t)cur.q;
                 h.reserved0 = 0;
                 h.reserved1 = 0;
                 h.sum = conf;
@@ -1146,14 +1190,7 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
         dl_first = false;
 #endif
         __builtin_amdgcn_wave_barrier();
-        if (HT_DEEP_DYNAMIC) {
-            uint32_t po = 760u;
-            asm volatile("" : "+s"(po));  // an address the optimiser cannot match with the store above: a real LDS read, not a register held across the window
-            // the k-th entry handed out by counter c is nwaves + HT_DEEP_CTRS * k + c
-            e = nwaves + HT_DEEP_CTRS * (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t *>(patch + po)) + (wave & (HT_DEEP_CTRS - 1u));
-        } else {
-            e += nwaves;
-        }
+        e = e_next;
     }
 }
 

@@ -85,3 +85,45 @@ def test_oversized_optional_scalars_are_dropped_not_the_line():
     for k in CONTRACT:
         assert k in got, k
     assert got["n_gpus"] == 8 and got["cpu_baseline_note"] == "N = 1 only"
+
+
+def test_pmc_constants_are_tied_to_the_build(tmp_path):
+    """profiles/traffic.json's counters are constants of the build they were measured on (round-5 verdict: nothing tied them to the library
+    being timed).  tools/gpu_pmc.sh records the code-object fingerprint of the profiled library, collect_profiles.py stores it as `_build`,
+    and load_pmc compares it with the library bench.py loads: same build -> fresh; another pyramid code object -> ['pyramid']; a file
+    without a fingerprint -> stale (None).  A stale record flags the line and drops valu_issue_frac."""
+    import os
+
+    from benchlib import common, fingerprint
+
+    lib = fingerprint.default_lib()
+    if not os.path.exists(lib):
+        import pytest
+
+        pytest.skip("library not built")
+    now = fingerprint.code_objects(lib)
+    assert set(now) == {"pyramid", "scan", "camshift"} and all(len(v) == 16 for v in now.values())
+    doc = {"c2": {"per_step": {"gray": 1, "resample": 2}, "valu_per_step": 3}, "c3": {"per_step": {"cs_track": 5}, "valu_per_step": 7}}
+
+    def load(build, wl="c2"):
+        p = tmp_path / "traffic.json"
+        p.write_text(json.dumps(dict(doc, **({"_build": build} if build is not None else {}))))
+        return common.load_pmc(wl, lib=lib, path=str(p))
+
+    per, valu, stale = load(now)
+    assert per == {"gray": 1, "resample": 2} and valu == 3 and stale == []
+    assert load(dict(now, pyramid="0" * 16))[2] == ["pyramid"]
+    assert load(dict(now, camshift="0" * 16))[2] == []  # C2's counters do not depend on the camshift code object ...
+    assert load(dict(now, camshift="0" * 16), "c3")[2] == ["camshift"]  # ... C3's do
+    assert load(None)[2] is None
+    # the committed file: whatever its state, load_pmc answers without raising and names the stale units
+    per, valu, stale = common.load_pmc("c2")
+    assert stale is None or isinstance(stale, list)
+    # a stale record in the line: flagged, valu_issue_frac absent
+    prim, sub = _tree()
+    prim["roofline"]["traffic_stale"] = True
+    prim["traffic_stale"] = True
+    prim.pop("valu_issue")
+    line = bl.compose("m", prim, sub, 1, {})
+    assert line["traffic_stale"] is True and line["roofline"]["traffic_stale"] is True and "stale" in line["roofline"]["traffic_source"]
+    assert "valu_issue_frac" not in line and "valu_issue_frac_720p" in line and "traffic_stale_720p" not in line

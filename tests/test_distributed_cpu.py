@@ -106,6 +106,34 @@ def test_bench_gpus_n_launches_n_ranks():
     assert len(r.stdout.strip().splitlines()[-1]) < 2000  # the one line stays a headline (benchlib/line.py)
 
 
+def test_bench_gpus_8_stub_is_cheap_and_loud():
+    """The driver's N = 8 run: `python bench.py --gpus 8` must come up, finish well inside a minute of plumbing and print ONE line with
+    ranks 8 (stand-in step, gloo); the line carries the group's init time (max over the ranks).  And a group that cannot come up inside
+    the budget ends with a message and a non-zero exit code, not a hang: rank 1 of a 2-rank world that never gets its peer."""
+    import subprocess
+    import time
+
+    t0 = time.time()
+    r, line = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1"], {"HT_BENCH_STUB": "1"}, timeout=170)
+    wall = time.time() - t0
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert wall < 60.0, f"bench.py --gpus 8 (stub) took {wall:.0f} s"
+    assert line["n_gpus"] == 8 and line["ranks"] == 8 and line["allgather_verified"] is True
+    assert line["config"]["frames_total"] == 8 * line["config"]["frames_per_gpu"]
+    assert 0.0 <= line["rccl_init_s"] < 60.0
+    assert len([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]) == 1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HT_BENCH_STUB="1", WORLD_SIZE="2", RANK="1", LOCAL_RANK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HT_BENCH_INIT_BUDGET_S="3")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "did not come up within 3 s" in r.stderr, r.stderr[-1500:]
+    assert time.time() - t0 < 60.0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_bench_refuses_to_mislabel_the_gpu_count():
     """fewer GPUs than --gpus (here: none) is an error, not a silent 1-GPU run labelled n_gpus 1; so is a launcher whose
     WORLD_SIZE disagrees with --gpus"""

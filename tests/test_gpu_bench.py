@@ -53,10 +53,14 @@ def test_default_line_is_compact_and_complete(tmp_path):
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["dtype"] == "u8"
     r, c = line["roofline"], line["cpu_baseline"]
     assert r["bound"] == "hbm" and 0.05 < r["frac"] < 1.0 and r["peak"] == 8000.0 and r["avg_launch_ms"] > 0
-    assert r["traffic"] and "not this run" in r["traffic_source"]
+    # the PMC constants are tied to the build they were measured on (benchlib/fingerprint.py): a library built from other kernel sources
+    # than the committed counter pass makes the line say so and drop the figure derived from them
+    stale = bool(line.get("traffic_stale"))
+    assert r["traffic"] and ("stale" in r["traffic_source"] if stale else "not this run" in r["traffic_source"])
+    assert bool(r.get("traffic_stale")) == stale and (("valu_issue_frac" in line) != stale)
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and len(c["sample"]) <= 200
     for k in ("value_720p", "ms_per_step_720p", "north_star_720p_vs_reference_js", "c3_value", "c5_value", "path_hbm_frac",
-              "wall_hbm_frac", "valu_issue_frac", "depth1_ms_per_step", "depth1_ms_per_step_720p", "pcie_inclusive_value",
+              "wall_hbm_frac", "depth1_ms_per_step", "depth1_ms_per_step_720p", "pcie_inclusive_value",
               "pcie_inclusive_value_720p", "latency_1frame_320x240_ms", "latency_1frame_1280x720_ms", "exchange_cost_frac_c2",
               "rccl_init_s", "parity_exact", "bench_wall_s", "sub_file"):
         assert k in line, k

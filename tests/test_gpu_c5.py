@@ -90,15 +90,17 @@ def test_c5_shape_feeds_in_one_context_vs_oracle(cascade, feeds):
         dev.free()
 
 
+@pytest.mark.parametrize("cs_flags", [1, 0], ids=["marks", "event"])
 @pytest.mark.parametrize("feeds", [8, 1])
-def test_c5_pipelined_loop_as_the_bench_issues_it(cascade, feeds):
+def test_c5_pipelined_loop_as_the_bench_issues_it(cascade, feeds, cs_flags):
     """bench.py's TIMED C5 loop (round 5): two track steps outstanding; a detect step is enqueued right behind them BEFORE their
     results are collected, its best faces are collected after, initTracker no longer waits for the stream (rects staged in pinned
     memory) and the next track step is enqueued right behind it; completion of an enqueue-only track call is a mark the kernel writes
-    into the pinned slot (no event).  91 steps = three detect steps; every best face and every track object == the oracle's."""
+    into the pinned slot (no event; option cs_flags=0 — the event completion path of the cluster track — returns the same objects).
+    91 steps = three detect steps; every best face and every track object == the oracle's."""
     K, steps = feeds, 91
     uniq = synth.stream_feed_frames(NUNIQ, W, H, 0)
-    c = Context()
+    c = Context(options=f"cs_flags={cs_flags}")
     dev = c5_device_steps(uniq, K)
     sbytes = K * W * H * 4
     try:

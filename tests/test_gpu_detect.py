@@ -168,6 +168,27 @@ def test_mixed_batch_hits_vs_oracle(ctx, cascade, mode):
     assert hits2.tobytes() == hits.tobytes()
 
 
+@pytest.mark.parametrize("fp_sparse", [0, 1])
+def test_sparse_stage_schedules_return_the_same_hits(cascade, fp_sparse):
+    """option fp_sparse: the tile kernel's sparse stages as four feature slices (0) or one lane per (window, feature) pair when <= 256
+    pairs are left (1, the default) — the header promises identical results for every option key: raw hits incl. the binary64
+    confidence and the stage counters equal the oracle's with either (only the default had a parity test)."""
+    w, h, n = 320, 240, 24
+    frames = synth.mixed_batch(n, w, h, seed0=777)
+    c = Context(options=f"fp_sparse={fp_sparse}")
+    try:
+        hits, counts = c.detect_raw(frames, flags=HT_SCAN_STATS)
+        ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(n)])
+        assert len(ref) > 50
+        assert_hits_equal(hits, ref)
+        sp = np.zeros(cascade.count + 1, dtype=np.int64)
+        for i in range(n):
+            ho.detect_raw(frames[i], cascade.blob, stage_pass=sp)
+        assert np.array_equal(c.stage_counts().astype(np.int64), sp)
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("grid", [1, 2, 3, 17])
 def test_deep_kernel_grid_option_never_loses_queue_entries(cascade, grid):
     """k_scan_deep_lds hands queue entries out through 16 work counters, counter c serving the entries
@@ -228,6 +249,48 @@ def test_destroying_the_owner_of_a_shared_frame_buffer_keeps_it_alive_for_its_bi
         binder.close()  # releases the orphaned buffer
 
 
+def test_orphaned_frame_buffer_is_released_when_its_last_binder_moves_away(cascade):
+    """a shared frame buffer that outlived its owner (an orphan) used to be reclaimed only inside a LATER ht_destroy — a
+    host whose last binder re-binds elsewhere and never destroys a context kept the HBM for the life of the process.  Orphans are now
+    swept whenever a context's frames move: 512 MB come back as soon as the binder uploads frames of its own."""
+    import ctypes as C
+
+    import torch
+
+    from headtrackr_amd import native
+
+    L = native.lib()
+    w, h, n = 320, 240, 4
+    frames = np.ascontiguousarray(synth.mixed_batch(n, w, h, seed0=5))
+    ref = np.concatenate([oracle_hits(frames[i], cascade, i) for i in range(n)])
+    big = 512 << 20
+    owner, binder = Context(), Context()
+    try:
+        torch.cuda.synchronize()
+        p = C.c_void_p()
+        assert L.ht_device_alloc(owner._h, big, C.byref(p)) == 0
+        assert L.ht_device_upload(owner._h, p, frames.ctypes.data, frames.nbytes) == 0
+        binder.set_geometry(w, h, n)
+        binder.bind_device(p.value, n)
+        binder.detect_enqueue(0)
+        hits, _ = binder.detect_collect()
+        assert_hits_equal(hits, ref)
+        owner.close()  # the buffer becomes an orphan: the binder is still bound inside it
+        binder.detect_enqueue(0)  # still valid memory
+        hits, _ = binder.detect_collect()
+        assert_hits_equal(hits, ref)
+        torch.cuda.synchronize()
+        free_orphaned = torch.cuda.mem_get_info()[0]
+        binder.upload(frames)  # the last binder moves to a buffer of its own: the orphan goes, here and now
+        assert torch.cuda.mem_get_info()[0] > free_orphaned + big // 2
+        binder.detect_enqueue(0)
+        hits, _ = binder.detect_collect()
+        assert_hits_equal(hits, ref)
+    finally:
+        owner.close()
+        binder.close()
+
+
 def test_gray_in_r_entry(ctx, cascade):
     """HT_INPUT_GRAY_IN_R == calling ccv.detect_objects on an already gray canvas"""
     frame = synth.face_frame(320, 240, [(100, 60, 96)])
@@ -237,14 +300,16 @@ def test_gray_in_r_entry(ctx, cascade):
     assert len(a) == 9 and a.tobytes() == b.tobytes()
 
 
+@pytest.mark.parametrize("cap", ["", ",rs_tailcap=32768", ",rs_tailcap=1000"], ids=["small-batch-cap", "cap-32768", "cap-1000"])
 @pytest.mark.parametrize("table", ["0", "1", "2"], ids=["binary64-tail", "table-tail", "table-tail-small"])
 @pytest.mark.parametrize("w,h", [(320, 240), (201, 157), (38, 30)])
-def test_pyramid_both_tail_kernels(w, h, table):
+def test_pyramid_both_tail_kernels(w, h, table, cap):
     """The last generations are built by one of the tail kernels, chosen by batch size: the round-1 one (taps re-derived in
     registers, binary64 lerps) and the table-driven one (host tap tables, binary32 estimate + binary64 fallback, integer box
     means; compact taps in LDS, or — the small-footprint form — read from L2).  Forced here on the same inputs: every plane
-    equals the oracle's with each."""
-    c = Context(options=f"rs_tailtable={table}")
+    equals the oracle's with each.  Which generations the tail takes depends on its pixel cap — 32 768 for batches that fill the chip,
+    4 000 for batches of <= 16 frames like this one (round 6), forced here to both and to 1 000."""
+    c = Context(options=f"rs_tailtable={table}{cap}")
     try:
         _check_pyramid(c, w, h)
     finally:

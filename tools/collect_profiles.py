@@ -17,7 +17,7 @@ G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 # timer name (HtProfScope) of every kernel = the keys of bench.py's kernel_ms_per_step
-timer = {"k_gray_linear": "gray", "k_gray_rows": "gray", "k_resample": "resample", "k_resample_tail": "resample", "k_resample_tail_f64": "resample", "k_pyramid_frame": "resample",
+timer = {"k_gray_linear": "gray", "k_gray_rows": "gray", "k_resample": "resample", "k_resample_bands": "resample", "k_resample_tail": "resample", "k_resample_tail_f64": "resample", "k_pyramid_frame": "resample",
          "k_scan_tiles": "scan_tiles", "k_scan_deep": "scan_deep", "k_scan_deep_lds": "scan_deep", "k_cs_track_fused": "cs_track", "k_cs_hist": "cs_hist",
          "k_cs_meanshift": "cs_meanshift", "k_cs_meanshift_cluster": "cs_meanshift", "k_cs_lut": "cs_lut", "k_cs_init": "cs_init", "k_cs_init_rows": "cs_init"}
 traffic = {"_note": "HBM bytes from rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes, tools/gpu_pmc.sh): bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.  "
@@ -84,6 +84,18 @@ for name in ("default", "driver", "driver_sub", "c5"):
     bj = os.path.join(G, f"bench_{name}.json")
     if os.path.exists(bj):
         shutil.copy(bj, os.path.join(P, f"{tag}_bench_{name}.json"))
+builds = {}
+for wl in ("c2", "c4", "c3"):
+    bj = os.path.join(G, f"pmc_build_{wl}.json")
+    if os.path.exists(bj) and wl in traffic:
+        builds[wl] = json.load(open(bj))
+if builds:
+    vals = list(builds.values())
+    if any(v != vals[0] for v in vals):
+        raise SystemExit(f"the PMC passes of this gpurun_out/ were taken on different builds: {builds}")
+    traffic["_build"] = vals[0]  # code-object fingerprint (benchlib/fingerprint.py) of the library the counters were measured on
+else:
+    print("WARNING: no pmc_build_*.json next to the counter passes: traffic.json carries no _build and bench.py will call it stale")
 if len(traffic) > 1:
     nf = {"c2": (256, 320, 240), "c4": (128, 1280, 720), "c3": (256, 320, 240)}
     traffic["gray_check"] = {wl: {"measured": traffic[wl]["per_step"].get("gray"), "known": nf[wl][0] * nf[wl][1] * nf[wl][2] * 5} for wl in traffic if wl in nf}

@@ -4,6 +4,8 @@ set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $OUT
 export TMPDIR=/tmp
 WL=${PMC_WL:-c2}
+# the build the counters belong to (benchlib/fingerprint.py): tools/collect_profiles.py stores it as traffic.json's _build
+python -c "import json,sys; sys.path.insert(0,'$GRAFT_REPO_ROOT'); from benchlib import fingerprint as f; json.dump(f.code_objects(), open('$OUT/pmc_build_${WL}.json','w'))"
 cd /tmp
 i=0
 for set in "${@:-SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_INST_ANY}"; do

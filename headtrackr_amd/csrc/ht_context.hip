@@ -322,6 +322,7 @@ static bool apply_options(ht_ctx *c, const std::string &opts, std::string &why) 
         else if (key == "deep_bias") c->deep_bias = (uint32_t)std::max(0, iv);
         else if (key == "deep_v") c->dbg_deep_v = iv;
         else if (key == "cs_flags") c->cs_flags = iv != 0;
+        else if (key == "cs_sync_ring") c->cs_sync_ring = iv != 0;
         else if (key == "fp_sparse") c->fp_sparse = iv != 0;
         else if (key == "deep_grid") c->deep_grid = std::max(1, iv);
         else if (key == "split") c->opt_split = std::max(1, iv);

@@ -371,7 +371,12 @@ struct ht_ctx {
     ht_cs_trackobj *d_cs_out = nullptr;
     double *d_cs_lut = nullptr, *d_cs_parts = nullptr;  // cluster mean-shift: per-stream weight LUT, partial-sum exchange slots
     bool cs_cluster = true;                              // option cs_cluster=0 disables the cluster path
-    uint32_t cs_cluster_min_px = 400000;                 // frames at least this large take it (option cs_cluster_min_px)
+    uint32_t cs_cluster_min_px = 10000;                  // frames at least this large take it (option cs_cluster_min_px).  Round 6, rocprofv3 kernel trace of
+                                                         // track() calls in turn (tools/gpu_cs_one_stream_trace.sh), device us per call, cluster / one workgroup per
+                                                         // stream: 320x240 x 1: 19.1 / 19.1, x 8: 20.0 / 20.6; 480x360 x 1: 18.6 / 24.7, x 16: 20.5 / 29.8; 640x480 x 1:
+                                                         // 20.8 / 31.2, x 8: 20.5 / 35.1; 1280x720 x 8: 22.4 / 40.9 — and its calls are completed by marks in the pinned
+                                                         // slot instead of an event: wall per synchronous call at 320x240 21.5 / 30.2 us (tools/gpu_cs_wall.py).  The
+                                                         // threshold was 400 k pixels until then: VGA and the reference's own 320x240 canvas took the slower path
     ht_cs_trackobj *d_cs_seq_out = nullptr;  // ht_camshift_track_sequence: [calls][streams] results, one D2H at the end
     size_t cs_seq_cap = 0;
     // the sequence enqueued with out == NULL that ht_camshift_sequence_collect may fetch (n == 0: none pending)
@@ -396,6 +401,7 @@ struct ht_ctx {
     hipEvent_t ev_cs_rects = nullptr;  // its copy to the device has been issued and completed
     uint32_t cs_flag_seq = 0;
     bool cs_flags = true;
+    bool cs_sync_ring = true;  // option cs_sync_ring=0: a synchronous track call copies its results back and synchronises the stream (A/B)
     HtCsSlot cs_ring[HT_CS_RING];
     int cs_ring_head = 0, cs_ring_count = 0, cs_ring_streams = 0;
     uint32_t *h_cs_err_direct = nullptr;  // pinned word the cluster kernel itself sets when a barrier times out (read with a ring slot: no copy)

@@ -71,6 +71,7 @@ typedef struct ht_config {
                              *   cs_cluster=0|1, cs_cluster_min_px=N, cs_region=N                 cluster / LDS-region paths of the few-stream schedule
                              *   cs_barrier_budget=N  shader-clock cycles a cluster exchange may wait before the call fails with HT_ERR_STATE
                              *   cs_flags=0|1         enqueue-only track calls of the cluster path are completed by marks in the pinned slot (1) or an event
+                             *   cs_sync_ring=0|1     a synchronous track call takes the enqueue-only route and collects at once (1) or copies back + synchronises (0)
                              *   fp_sparse=0|1        tile kernel: sparse stages one lane per (window, feature) pair when <= 256 pairs are left (1)
                              *   graph_max_frames=N   batches up to N frames replay a captured hipGraph (256; 0 = never)
                              *   split=S, deep_bias=B, deep_v=2|4, deep_grid=N                    tile kernel -> deep kernel hand-off (grid kept >= 16 wavefronts)

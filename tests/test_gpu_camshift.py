@@ -38,14 +38,16 @@ def _write_parity():
 atexit.register(_write_parity)
 
 
-SCHEDULES = {"chunked": "cs_fused_min=1000000", "fused": "cs_fused_min=1,cs_fused_nt=1024", "fused512": "cs_fused_min=1,cs_fused_nt=512"}
+SCHEDULES = {"chunked": "cs_fused_min=1000000,cs_cluster=0", "fused": "cs_fused_min=1,cs_fused_nt=1024", "fused512": "cs_fused_min=1,cs_fused_nt=512",
+             "cluster": "cs_fused_min=1000000,cs_cluster_min_px=1"}
 
 
 @pytest.fixture(scope="module", params=list(SCHEDULES))
 def ctx(request):
-    """every test of this module runs on the camshift schedules: chunk histograms + one mean-shift workgroup per stream (few
-    streams), and the single-launch kernel that is chosen for >= 192 streams (forced here with option cs_fused_min=1) in its
-    1024-thread form (one stream owns a CU) and its 512-thread form (two workgroups per CU)"""
+    """every test of this module runs on the camshift schedules: chunk histograms + one mean-shift workgroup per stream (few small
+    streams), the single-launch kernel that is chosen for >= 192 streams (forced here with option cs_fused_min=1) in its 1024-thread
+    form (one stream owns a CU) and its 512-thread form (two workgroups per CU), and chunk histograms + LUT + a cluster of workgroups per
+    stream (<= 64 streams of frames from 200 k pixels on; forced here for every size with cs_cluster_min_px=1)"""
     c = Context(options=SCHEDULES[request.param])
     yield c
     c.close()

@@ -647,6 +647,17 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
 #define HT_RSB_WPS 8
 #endif
 constexpr int RSB_BAND = 4096;  // LDS bytes per wavefront = four 1 KB LDS-DMA instructions = 25.6 rows of RS_SP bytes
+#if defined(HT_RS_PHASES)  // tools/gpu_rsb_phases.py: shader-clock sums per phase of a WAVEFRONT's frame iteration (there is no workgroup phase in the loop)
+__device__ unsigned long long g_rsb_ph[8];  // [0] iterations, [1] pixels, [2] DMA issue, [3] wait for the band, [4] stores, [5] workgroups, [6] record -> first loop top
+#define RSB_T(var_)                                     \
+    do {                                                \
+        __builtin_amdgcn_sched_barrier(0);              \
+        var_ = __builtin_readcyclecounter();            \
+        __builtin_amdgcn_sched_barrier(0);              \
+    } while (0)
+#else
+#define RSB_T(var_)
+#endif
 typedef __attribute__((address_space(3))) void rs_lds_void;
 template <int RPT>
 __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResampleJob *__restrict__ tiles, uint8_t *__restrict__ arena,
@@ -657,6 +668,10 @@ __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResa
     __shared__ RsTap s_col[RS_TW], s_row[TH];
     uint32_t gidx, blk;
     if (!xcd_item(blocks_per_frame, ngroups, &gidx, &blk)) return;
+#ifdef HT_RS_PHASES
+    unsigned long long rsb_t_entry = 0, rsb_t0 = 0, rsb_t1 = 0, rsb_t2 = 0, rsb_t3 = 0, rsb_t4 = 0;
+    RSB_T(rsb_t_entry);
+#endif
     const HtResampleJob J = tiles[blk];
     const uint32_t f0 = gidx * group_frames, f1 = min(f0 + group_frames, nframes);
     const int tid = (int)threadIdx.x;
@@ -732,6 +747,10 @@ __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResa
                 fbase += arena_stride;
 #pragma unroll
                 for (int q = 0; q < NP; q++) asm volatile("" : "+v"(roff[q]));
+#ifdef HT_RS_PHASES
+                if (f == f0 && l == 0 && w == 0) atomicAdd(&g_rsb_ph[5], 1ull), atomicAdd(&g_rsb_ph[6], __builtin_readcyclecounter() - rsb_t_entry);
+#endif
+                RSB_T(rsb_t0);
                 uint32_t o[NP];
                 if (BOX) {
 #pragma unroll
@@ -791,6 +810,11 @@ __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResa
                         o[q] = rv[q] ? (oq & pxmask) : 0u;
                     }
                 }
+#ifdef HT_RS_PHASES
+#pragma unroll
+                for (int q = 0; q < NP; q++) asm volatile("" ::"v"(o[q]));
+#endif
+                RSB_T(rsb_t1);
                 if (f + 1 < f1) {
                     // every LDS read of this frame's band has returned (o[] depends on all of them): the band may be overwritten.  The wait
                     // below is for the DMA alone — this frame's stores are issued behind it, the previous frame's are a pixel phase old.
@@ -798,11 +822,20 @@ __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResa
                     // vmcnt(0) in front of the next frame's first LDS read)
                     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
                     RSB_DMA(fr, (uint32_t)arena_stride);
+                    RSB_T(rsb_t2);
                     __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+                    RSB_T(rsb_t3);
                 }
 #pragma unroll
                 for (int q = 0; q < NP; q++)
                     if (st[q]) __builtin_amdgcn_raw_buffer_store_b32(o[q], fr, doff, (uint32_t)(4 * q * dst_stride), 0);
+#ifdef HT_RS_PHASES
+                RSB_T(rsb_t4);
+                if (l == 0 && f + 1 < f1) {  // one sample per wavefront and frame iteration (the last one of a group has no DMA phase)
+                    atomicAdd(&g_rsb_ph[0], 1ull), atomicAdd(&g_rsb_ph[1], rsb_t1 - rsb_t0), atomicAdd(&g_rsb_ph[2], rsb_t2 - rsb_t1);
+                    atomicAdd(&g_rsb_ph[3], rsb_t3 - rsb_t2), atomicAdd(&g_rsb_ph[4], rsb_t4 - rsb_t3);
+                }
+#endif
             }
         };
         using std::integral_constant;
@@ -1180,6 +1213,17 @@ ht_status ht_launch_whitebalance(ht_ctx *c, double *d_out, bool zero) {
 }
 
 #ifdef HT_RS_PHASES
+// k_resample_bands: out8 = g_rsb_ph (see there)
+extern "C" int ht_debug_rsb_phases(unsigned long long *out8, int reset) {
+    unsigned long long h[8];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rsb_ph), sizeof(h)) != hipSuccess) return 1;
+    for (int i = 0; i < 8; i++) out8[i] = h[i];
+    if (reset) {
+        std::memset(h, 0, sizeof(h));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_rsb_ph), h, sizeof(h)) != hipSuccess) return 1;
+    }
+    return 0;
+}
 // sums per phase over all recorded frame iterations: out16[i] = cycles between stamp i-1 and stamp i (i = 3..6; 2 = from the previous
 // iteration's stamp 6), out16[8 + i] = samples
 extern "C" int ht_debug_rs_phases(unsigned long long *out16, int reset) {

@@ -76,7 +76,7 @@ for name in ("tile_timeline_c2.txt", "tile_timeline_c4.txt", "rs_phases_c2.txt",
             print(f"REFUSED {name}: not a timeline (traceback / error / empty)")
             continue
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
-for name in ("cs_step.txt", "kernel_times.txt", "host_post.txt"):
+for name in ("cs_step.txt", "kernel_times.txt", "host_post.txt", "one_frame_trace.txt", "launch_chain.txt", "cs_wall.txt", "ab_bands.txt", "pmc_ab.txt"):
     src = os.path.join(G, name)
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))

@@ -22,6 +22,10 @@ for o in "" host_threads=0; do timeout 120 python tools/gpu_kernel_times.py c2 $
 timeout 120 python tools/gpu_kernel_times.py c4 2>/dev/null | tail -1 >> $OUT/kernel_times.txt; cat $OUT/kernel_times.txt
 for f in 8 1; do timeout 200 python tools/gpu_cs_step.py $f 2>/dev/null | tail -1 >> $OUT/cs_step.txt; done; cat $OUT/cs_step.txt
 timeout 300 bash tools/gpu_c5_trace.sh cs_flags=1 > $OUT/c5_trace.txt 2>&1; tail -3 $OUT/c5_trace.txt
+# single-frame / single-stream calls in turn: kernel traces (rocprofv3 --kernel-trace only) and wall clocks
+{ for g in "320 240 1" "1280 720 1" "1920 1080 1" "1920 1080 8"; do timeout 200 bash tools/gpu_one_frame_trace.sh $g; done; } > $OUT/one_frame_trace.txt 2>&1
+{ timeout 200 ./tools/micro/launch_chain_bench; } > $OUT/launch_chain.txt 2>&1
+{ timeout 200 python tools/gpu_cs_wall.py; timeout 200 python tools/gpu_cs_wall.py cs_sync_ring=0; for g in "320 240 1" "640 480 1" "1920 1080 1"; do timeout 200 bash tools/gpu_cs_one_stream_trace.sh $g; done; } > $OUT/cs_wall.txt 2>/dev/null
 if [ "${RUN_PROF:-1}" = 1 ]; then
 cd /tmp
 for wl in c2 c4 c3 c5; do
@@ -39,7 +43,7 @@ done
 fi
 # shader-clock phase timelines of the two big kernels (alt/tltl.so = -DHT_TILE_TIMELINE, alt/rsph.so = -DHT_RS_PHASES, built by
 # tools/build_alt.py from the CURRENT sources: a stale variant is refused, stderr never lands in the evidence files)
-for pair in "tltl gpu_tile_timeline tile_timeline" "rsph gpu_rs_phases rs_phases"; do
+for pair in "tltl gpu_tile_timeline tile_timeline" "rsph gpu_rsb_phases rs_phases"; do
   set -- $pair
   if python tools/build_alt.py --check $1 > /dev/null; then
     for wl in c2 c4; do

@@ -648,7 +648,9 @@ __global__ __launch_bounds__(256, HT_RS_WPS) void k_resample(const HtResampleJob
 #endif
 constexpr int RSB_BAND = 4096;  // LDS bytes per wavefront = four 1 KB LDS-DMA instructions = 25.6 rows of RS_SP bytes
 #if defined(HT_RS_PHASES)  // tools/gpu_rsb_phases.py: shader-clock sums per phase of a WAVEFRONT's frame iteration (there is no workgroup phase in the loop)
-__device__ unsigned long long g_rsb_ph[8];  // [0] iterations, [1] pixels, [2] DMA issue, [3] wait for the band, [4] stores, [5] workgroups, [6] record -> first loop top
+__device__ unsigned long long g_rsb_ph[256][8];  // per shard (blockIdx & 255): [0] iterations, [1] pixels, [2] DMA issue, [3] wait for the band, [4] stores, [5] workgroups, [6] record -> first loop top
+// sums are kept in registers and added ONCE per wavefront at its exit: an atomic per phase and iteration sits in the vector-memory queue in front of the
+// next iteration's s_waitcnt vmcnt(0) and was what the first version of these stamps measured ("wait 155 k cycles")
 #define RSB_T(var_)                                     \
     do {                                                \
         __builtin_amdgcn_sched_barrier(0);              \
@@ -669,7 +671,7 @@ __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResa
     uint32_t gidx, blk;
     if (!xcd_item(blocks_per_frame, ngroups, &gidx, &blk)) return;
 #ifdef HT_RS_PHASES
-    unsigned long long rsb_t_entry = 0, rsb_t0 = 0, rsb_t1 = 0, rsb_t2 = 0, rsb_t3 = 0, rsb_t4 = 0;
+    unsigned long long rsb_t_entry = 0, rsb_t0 = 0, rsb_t1 = 0, rsb_t2 = 0, rsb_t3 = 0, rsb_t4 = 0, rsb_acc[7] = {0, 0, 0, 0, 0, 0, 0};
     RSB_T(rsb_t_entry);
 #endif
     const HtResampleJob J = tiles[blk];
@@ -748,7 +750,7 @@ __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResa
 #pragma unroll
                 for (int q = 0; q < NP; q++) asm volatile("" : "+v"(roff[q]));
 #ifdef HT_RS_PHASES
-                if (f == f0 && l == 0 && w == 0) atomicAdd(&g_rsb_ph[5], 1ull), atomicAdd(&g_rsb_ph[6], __builtin_readcyclecounter() - rsb_t_entry);
+                if (f == f0 && w == 0) rsb_acc[5] = 1ull, rsb_acc[6] = __builtin_readcyclecounter() - rsb_t_entry;
 #endif
                 RSB_T(rsb_t0);
                 uint32_t o[NP];
@@ -831,12 +833,18 @@ __global__ __launch_bounds__(256, HT_RSB_WPS) void k_resample_bands(const HtResa
                     if (st[q]) __builtin_amdgcn_raw_buffer_store_b32(o[q], fr, doff, (uint32_t)(4 * q * dst_stride), 0);
 #ifdef HT_RS_PHASES
                 RSB_T(rsb_t4);
-                if (l == 0 && f + 1 < f1) {  // one sample per wavefront and frame iteration (the last one of a group has no DMA phase)
-                    atomicAdd(&g_rsb_ph[0], 1ull), atomicAdd(&g_rsb_ph[1], rsb_t1 - rsb_t0), atomicAdd(&g_rsb_ph[2], rsb_t2 - rsb_t1);
-                    atomicAdd(&g_rsb_ph[3], rsb_t3 - rsb_t2), atomicAdd(&g_rsb_ph[4], rsb_t4 - rsb_t3);
+                if (f + 1 < f1) {  // one sample per wavefront and frame iteration (the last one of a group has no DMA phase)
+                    rsb_acc[0] += 1ull, rsb_acc[1] += rsb_t1 - rsb_t0, rsb_acc[2] += rsb_t2 - rsb_t1, rsb_acc[3] += rsb_t3 - rsb_t2, rsb_acc[4] += rsb_t4 - rsb_t3;
                 }
 #endif
             }
+#ifdef HT_RS_PHASES
+            if (l == 0) {
+#pragma unroll
+                for (int i = 0; i < 7; i++)
+                    if (rsb_acc[i]) atomicAdd(&g_rsb_ph[blockIdx.x & 255u][i], rsb_acc[i]);
+            }
+#endif
         };
         using std::integral_constant;
         if (mode & 1u) {
@@ -1215,9 +1223,11 @@ ht_status ht_launch_whitebalance(ht_ctx *c, double *d_out, bool zero) {
 #ifdef HT_RS_PHASES
 // k_resample_bands: out8 = g_rsb_ph (see there)
 extern "C" int ht_debug_rsb_phases(unsigned long long *out8, int reset) {
-    unsigned long long h[8];
+    static unsigned long long h[256][8];
     if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rsb_ph), sizeof(h)) != hipSuccess) return 1;
-    for (int i = 0; i < 8; i++) out8[i] = h[i];
+    for (int i = 0; i < 8; i++) out8[i] = 0;
+    for (int sh = 0; sh < 256; sh++)
+        for (int i = 0; i < 8; i++) out8[i] += h[sh][i];
     if (reset) {
         std::memset(h, 0, sizeof(h));
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_rsb_ph), h, sizeof(h)) != hipSuccess) return 1;

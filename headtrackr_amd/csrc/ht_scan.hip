@@ -996,11 +996,22 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
     // Now the wavefront's first entry is requested before the table copy (it needs nothing from it), entries carry their plane origins,
     // and every further entry is requested as soon as its index is known, a whole window ahead: one round trip (the gathers) per window.
     DeepEntry ent = deep_entry(queue, min(wave, n - 1u));
-    for (uint32_t i = threadIdx.x; i < packed_count * 2u; i += blockDim.x) tab[i] = reinterpret_cast<const uint4 *>(packed)[i];
+    // The table copy is LDS-DMA (gfx950 `global_load_lds_dwordx4`: 1 KB per instruction straight into LDS, no registers) and is NOT waited
+    // for here: the first window's patch gathers are issued behind it and both arrive together — the workgroup barrier that publishes the
+    // table sits in front of the first window's stage passes (wavefronts without a window take it behind the loop).
+    {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        const uint32_t tab_bytes = packed_count * (uint32_t)sizeof(HtPackedFeature);
+        for (uint32_t c0 = wv * 1024u; c0 < tab_bytes; c0 += DEEPL_WAVES * 1024u) {
+            const uint32_t off = c0 + lane * 16u;
+            if (off < tab_bytes)
+                __builtin_amdgcn_global_load_lds((glb_void *)(reinterpret_cast<const uint8_t *>(packed) + off), (lds_void *)(dyn_lds + c0), 16, 0, 0);
+        }
+    }
     for (uint32_t i = threadIdx.x; i < (uint32_t)nstages * (sizeof(HtDevStage) / 16); i += blockDim.x)
         reinterpret_cast<uint4 *>(s_stages)[i] = reinterpret_cast<const uint4 *>(stages)[i];
-    __syncthreads();
-    DL_STAMP(1);
+    bool table_published = false;
     uint8_t *patch = per_wave + wv * (PATCH_BYTES + 512);
     double *sel_buf = reinterpret_cast<double *>(patch + PATCH_BYTES);
     unsigned long long *my_stats = stats ? stats + (size_t)(wave & (HT_STAT_SHARDS - 1)) * 64 : nullptr;
@@ -1076,6 +1087,12 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        if (!table_published) {  // wave-uniform; every wavefront of the workgroup passes exactly one of the two barriers
+            __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wavefront's share of the table has landed in LDS
+            __syncthreads();
+            table_published = true;
+            DL_STAMP(1);
+        }
         DL_STAMP(2);
         bool alive = true;
         double conf = 0.0;
@@ -1191,6 +1208,10 @@ __global__ __launch_bounds__(64 * DEEPL_WAVES, (2 * DEEPL_WAVES + 3) / 4) void k
 #endif
         __builtin_amdgcn_wave_barrier();
         e = e_next;
+    }
+    if (!table_published) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
     }
 }
 

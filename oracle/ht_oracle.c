@@ -515,6 +515,62 @@ typedef struct {
 static void ho_moments_calc(ho_moments *m, const uint8_t *rgba, int W, const double *weights, int x, int y, int w,
                             int h, int second) {
     memset(m, 0, sizeof(*m));
+#ifdef HO_MOMENTS_ROW_MAJOR /* NOT the reference's order: tools/cpu_cs_order_check.py builds this variant to ask whether a case's result depends on the
+                             * summation order at all (a track object that changes under it cannot be reproduced by ANY parallel reduction) */
+    for (int j = y; j < h; j++)
+        for (int i = x; i < w; i++) {
+            double vx = (double)(i - x), vy = (double)(j - y);
+            double val = weights[ho_bin(rgba + 4 * ((size_t)j * W + i))];
+            m->m00 += val;
+            m->m01 += vy * val;
+            m->m10 += vx * val;
+            if (second) {
+                m->m11 += vx * vy * val;
+                m->m02 += vy * vy * val;
+                m->m20 += vx * vx * val;
+            }
+        }
+    if (0)
+#endif
+#ifdef HO_MOMENTS_TWO_ACCUMULATORS /* the reference's loops with even and odd rows summed apart and added at the end: the smallest step towards a tree */
+    {
+        ho_moments p[2];
+        memset(p, 0, sizeof(p));
+        for (int i = x; i < w; i++)
+            for (int j = y; j < h; j++) {
+                double vx = (double)(i - x), vy = (double)(j - y);
+                double val = weights[ho_bin(rgba + 4 * ((size_t)j * W + i))];
+                ho_moments *q = &p[(j - y) & 1];
+                q->m00 += val;
+                q->m01 += vy * val;
+                q->m10 += vx * val;
+                if (second) {
+                    q->m11 += vx * vy * val;
+                    q->m02 += vy * vy * val;
+                    q->m20 += vx * vx * val;
+                }
+            }
+        m->m00 = p[0].m00 + p[1].m00, m->m01 = p[0].m01 + p[1].m01, m->m10 = p[0].m10 + p[1].m10;
+        m->m11 = p[0].m11 + p[1].m11, m->m02 = p[0].m02 + p[1].m02, m->m20 = p[0].m20 + p[1].m20;
+    }
+    if (0)
+#endif
+#ifdef HO_MOMENTS_REVERSED /* the reference's loops walked backwards (last column first, bottom row first): another order no reduction is obliged to avoid */
+    for (int i = w - 1; i >= x; i--)
+        for (int j = h - 1; j >= y; j--) {
+            double vx = (double)(i - x), vy = (double)(j - y);
+            double val = weights[ho_bin(rgba + 4 * ((size_t)j * W + i))];
+            m->m00 += val;
+            m->m01 += vy * val;
+            m->m10 += vx * val;
+            if (second) {
+                m->m11 += vx * vy * val;
+                m->m02 += vy * vy * val;
+                m->m20 += vx * vx * val;
+            }
+        }
+    if (0)
+#endif
     for (int i = x; i < w; i++) {
         double vx = (double)(i - x);
         for (int j = y; j < h; j++) {

@@ -287,3 +287,33 @@ def test_cluster_barrier_timeout_is_a_status_code():
     finally:
         c.close()
         good.close()
+
+
+def test_order_sensitive_call_lands_on_one_of_the_two_sides(ctx):
+    """A case the randomised soak of round 6 found (tools/gpu_soak.py, seed 1790745752; kept as tests/golden/camshift_tie_case.npz): in the third
+    mean-shift iteration of call 4 only ONE column of the 4-pixel-wide search window has non-zero weights, so xc = M10 / M00 is exactly 3 in real
+    arithmetic and `toint32(xc - 2)` is decided by the rounding noise of the binary64 sums — the reference's column-major loop gets 3.0000000000000004
+    (window moves right), the SAME loop with even and odd rows added apart gets the other side (tests/test_oracle_golden.py checks that on the CPU).
+    No parallel reduction can promise the reference's side of such a tie; every schedule must still return one of the two results, and calls 1 - 3,
+    which are not ties, exactly."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "camshift_tie_case.npz"))
+    frames, rect = z["frames"][0], tuple(int(v) for v in z["rects"][0])
+    h, w = frames.shape[1], frames.shape[2]
+    o = ho.Camshift(True)
+    o.init_tracker(frames[0], rect)
+    ctx.set_geometry(w, h, 1)
+    ctx.camshift_reserve(1)
+    ctx.upload(frames[0][None])
+    ctx.camshift_init([rect])
+    stats = []
+    for k in range(1, 5):
+        sw, to = o.track(frames[k])
+        ctx.upload(frames[k][None])
+        got = ctx.camshift_track(1, calc_angles=True)[0]
+        if k < 4:
+            check(got, sw, to, stats, where=("tie-case", 0, k))
+        else:
+            assert [float(to[f]) for f in ("x", "y", "width", "height")] == [37.0, 23.0, 0.0, 12.0] and [int(v) for v in sw] == [35, 15, 0, 13]  # the reference's side
+            g = [float(got[f]) for f in ("x", "y", "width", "height")] + [int(got[f]) for f in ("sw_x", "sw_y", "sw_width", "sw_height")]
+            assert g in ([37.0, 23.0, 0.0, 12.0, 35, 15, 0, 13], [36.0, 23.0, 0.0, 8.0, 34, 15, 0, 8]), g
+    assert_all_exact(stats, "tie case, calls 1 - 3")

@@ -232,3 +232,21 @@ def test_resample_binary32_estimate_stays_inside_its_error_budget():
         total += n
     assert worst < eps and worst < 6.9e-5 * 1.05, worst  # inside RS_EPS, and inside the analytic bound of the source
     assert trusted > 0.5 * total
+
+
+def test_camshift_tie_case_depends_on_the_summation_order():
+    """tests/golden/camshift_tie_case.npz (found by the GPU soak of round 6): the reference's own algorithm, summed in another order, returns another
+    track object for call 4 — so that call's result is a property of the pixel loop's rounding noise, not of the algorithm.  The oracle compiled as is
+    (column-major, camshift.js:79-120) against the same source with -DHO_MOMENTS_TWO_ACCUMULATORS (even and odd rows added apart): calls 1 - 3 identical,
+    call 4 on the two sides of the tie.  The GPU test of the same fixture accepts exactly these two results."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("cpu_cs_order_check", os.path.join(root, "tools", "cpu_cs_order_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    case = os.path.join(root, "tests", "golden", "camshift_tie_case.npz")
+    ref, alt = mod.run(case, []), mod.run(case, ["-DHO_MOMENTS_TWO_ACCUMULATORS"])
+    assert [r[2:] for r in ref[:3]] == [r[2:] for r in alt[:3]]
+    assert ref[3][2:] == ([37.0, 23.0, 0.0, 12.0], [35, 15, 0, 13]) and alt[3][2:] == ([36.0, 23.0, 0.0, 8.0], [34, 15, 0, 8])

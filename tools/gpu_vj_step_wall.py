@@ -18,7 +18,7 @@ c.camshift_reserve(4)
 rects = np.zeros(1, dtype=[("x", "<i4"), ("y", "<i4"), ("width", "<i4"), ("height", "<i4")])
 rects["x"], rects["y"], rects["width"], rects["height"] = W // 3, H // 4, min(W, H) // 3, min(W, H) // 3
 parts = {"upload": [], "detect": [], "init": [], "track": []}
-for i in range(400):
+for i in range(1500):
     vj = i % 30 == 0
     t0 = time.perf_counter()
     c.upload(fr)

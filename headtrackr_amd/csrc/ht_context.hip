@@ -714,19 +714,22 @@ static ht_status set_geometry_impl(ht_ctx *c, int32_t width, int32_t height, int
     // tail plan: from the first generation g0 on which every generation has <= HT_TAIL_MAX_JOBS jobs and all of them
     // together <= tail_cap destination pixels per frame, one workgroup per frame does the rest of the pyramid in one launch
     // (k_resample_tail) instead of one nearly empty launch per generation.
+    constexpr int HT_SMALL_BATCH = 48;
     // Small batches (a live feed's frame, the 8 feeds of a streaming step) are latency chains, not throughput: the tail kernel is ONE
     // workgroup per frame walking its generations behind barriers — 21 us for 17 k pixels of a single 320x240 frame, the longest kernel
     // of the call —, while a k_resample_bands launch of the same generation is 4.5 us on the otherwise idle chip.  rocprofv3 kernel
     // trace of single-frame calls (tools/gpu_one_frame_trace.sh, round 6): cap 32 768 -> 4 000 pixels takes 74.1 -> 63.5 us off the
     // device span at 320x240 (generation 4 as a launch, generations 5 - 7 in the tail) and 92.9 -> 79.3 us at 1920x1080 (no tail at all);
-    // batches that fill the chip keep the large cap (C2: cap 4 000 costs +3 % on the pyramid, no tail at all +19 %).
-    const uint64_t tail_cap = c->rs_tailcap_forced ? c->rs_tailcap : (max_batch <= 16 ? 4000u : c->rs_tailcap);
+    // batches that fill the chip keep the large cap (C2: cap 4 000 costs +3 % on the pyramid, no tail at all +19 %).  Where it ends, pipelined
+    // (three batches of 320x240 in flight / two of 1280x720, small plan against large): 24 frames +11 %, 32 +10.6 %, 48 +9.5 %, 64 +-0 %, 128 +-0 %;
+    // 720p: 16 frames +2 %, 32 +3 %.
+    const uint64_t tail_cap = c->rs_tailcap_forced ? c->rs_tailcap : (max_batch <= HT_SMALL_BATCH ? 4000u : c->rs_tailcap);
     // which tail kernel: measured (3 batches in flight), the table-driven binary32 tail (68 VGPRs, 35 KB LDS) is worth +4-5 % at
     // 128 x 720p but costs 3 % at 256 x 320x240, where its grid puts a 1024-thread workgroup on EVERY CU and its footprint keeps
     // the other batches' kernels from sharing them; the round-1 binary64 tail (41 VGPRs) is kept for batches that cover the chip.
     // Larger caps (generation 3 of C2 = 54 k pixels in the tail) lose with either kernel.
     // ... and for a handful of frames: 7.6 us against the table form's 10.3 for generations 5 - 7 of a single 320x240 frame (the same trace)
-    if (!c->tail_table_forced) c->tail_table = (max_batch <= 128 && max_batch > 16) ? 1 : 0;
+    if (!c->tail_table_forced) c->tail_table = (max_batch <= 128 && max_batch > HT_SMALL_BATCH) ? 1 : 0;
     c->tail_first_gen = 0;
     if (c->d_tail_jobs) (void)hipFree(c->d_tail_jobs), c->d_tail_jobs = nullptr;
     if (c->d_tail_prefix) (void)hipFree(c->d_tail_prefix), c->d_tail_prefix = nullptr;

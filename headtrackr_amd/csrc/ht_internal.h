@@ -296,7 +296,7 @@ struct ht_ctx {
     int tail_table = 1;  // k_resample_tail with host tap tables: 1 = compact taps in LDS, 2 = taps from L2 / small footprint; 0: the round-1 binary64 tail (option rs_tailtable)
     bool tail_table_forced = false;  // option rs_tailtable given: ht_set_geometry keeps it instead of choosing by batch size
     bool rs_nofast = false, rs_nosort = false, rs_notail = false, rs_gennames = false;  // options of the same names (A/B, cross-checks)
-    uint64_t rs_tailcap = 32768;     // destination pixels per frame the tail kernel takes at most (option rs_tailcap; batches <= 16 frames: 4 000 unless the option is given)
+    uint64_t rs_tailcap = 32768;     // destination pixels per frame the tail kernel takes at most (option rs_tailcap; batches <= 48 frames: 4 000 unless the option is given)
     bool rs_tailcap_forced = false;
     int rs_maxgen = 1 << 30;         // HT_DEBUG_KNOBS builds only (results stale): pyramid generations built
     bool force_rccl = false;         // option force_rccl: ht_allgather_* runs RCCL even with one rank

@@ -18,6 +18,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "c2"
 opts = (sys.argv[2] if len(sys.argv) > 2 else None) or None
 DEPTH = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 W, H, n = {"c2": (320, 240, 256), "c4": (1280, 720, 128)}[wl]
+n = int(os.environ.get("HT_KT_FRAMES", n))  # another batch size at the same frame size
 base = synth.mixed_batch(n, W, H, seed0=1234)
 dev = torch.from_numpy(base).cuda()
 ctxs = []

@@ -10,8 +10,9 @@
 //
 // HBM layout: the reference keeps 4-byte RGBA copies of every level but only ever reads byte 0 (ccv.js:171,173,
 // 191-192), so each plane is stored once as 1 byte/pixel (row stride = width rounded up to 4, plane base 256-B
-// aligned) inside a per-frame arena; frames are arena_stride bytes apart.  All kernels take the frame index from
-// blockIdx.y so a whole batch is one launch per dependency generation.
+// aligned) inside a per-frame arena; frames are arena_stride bytes apart.  A whole batch is one launch per dependency
+// generation: k_resample_bands (round 6: LDS-DMA into wave-private source bands; the default) or k_resample (register-staged
+// tile, option rs_bands=0), and one tail launch (k_resample_tail*) for the tiny last generations.
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

@@ -234,7 +234,9 @@ ht_status ht_detect_collect_best_requeue(ht_ctx *ctx, int32_t min_neighbors, ht_
 ht_status ht_camshift_reserve(ht_ctx *ctx, int32_t nstreams);
 /* initTracker (camshift.js:198-211) for streams [first, first+n) using bound frames [0, n) and one rect each. */
 ht_status ht_camshift_init_batch(ht_ctx *ctx, int32_t first, int32_t n, const ht_cs_rect *rects);
-/* track (camshift.js:213-312) for streams [first, first+n) on bound frames [0, n); out[n] (may be NULL: enqueue only). */
+/* track (camshift.js:213-312) for streams [first, first+n) on bound frames [0, n); out[n] (may be NULL: enqueue only).  With out != NULL the call
+ * returns the track objects; when no enqueue-only call is outstanding it takes the same route internally (pinned slot + completion marks, no
+ * device-to-host copy, no stream synchronisation: option cs_sync_ring) — the results are the same either way. */
 ht_status ht_camshift_track_batch(ht_ctx *ctx, int32_t first, int32_t n, int32_t calc_angles, ht_cs_trackobj *out);
 /* Results of the OLDEST outstanding ht_camshift_track_batch that was enqueued with out == NULL (same n): waits for that call only and
  * copies its track objects.  Up to 4 enqueue-only calls may be outstanding per context (a fifth fails with HT_ERR_STATE): their kernels

@@ -21,7 +21,7 @@ WORKLOAD_TEXT = {
     "c4": "C4: 1280x720 frames, full cascade detect incl. grouping + best face per frame, all-gather of best-face "
           "rects for N > 1",
 }
-TRAFFIC_SOURCE = "profiles/traffic.json (rocprofv3 PMC pass of an earlier run, not this run)"
+TRAFFIC_SOURCE = "profiles/traffic.json (rocprofv3 PMC pass of the same build — code-object fingerprint checked —, not this run)"
 
 
 class Env:

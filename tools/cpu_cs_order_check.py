@@ -19,7 +19,7 @@ VARIANTS = (("row-major", "-DHO_MOMENTS_ROW_MAJOR"), ("reversed", "-DHO_MOMENTS_
 
 
 def run(case, variant_flags):
-    """[(stream, call, [x, y, width, height], search window)] of every track() call of the case, oracle built with `variant_flags`"""
+    """[(stream, call, [x, y, width, height], search window, angle)] of every track() call of the case, oracle built with `variant_flags`"""
     from oracle import ht_oracle as ho
 
     real = (ho._SO, ho._lib)
@@ -36,7 +36,7 @@ def run(case, variant_flags):
             o.init_tracker(frames[s][0], rects[s])
             for k in range(1, frames.shape[1]):
                 sw, to = o.track(frames[s][k])
-                out.append((s, k, [float(to[f]) for f in ("x", "y", "width", "height")], [int(v) for v in sw]))
+                out.append((s, k, [float(to[f]) for f in ("x", "y", "width", "height")], [int(v) for v in sw], float(to["angle"])))
         return out
     finally:
         ho._SO, ho._lib = real  # back to the real oracle
@@ -47,8 +47,10 @@ if __name__ == "__main__":
     sensitive = set()
     for name, flag in VARIANTS:
         b = run(sys.argv[1], [flag])
-        for (s, k, ta, swa), (_, _, tb, swb) in zip(a, b):
-            if ta != tb or swa != swb:
+        for (s, k, ta, swa, aa), (_, _, tb, swb, ab) in zip(a, b):
+            da = 0.0 if (aa != aa and ab != ab) else abs(aa - ab)
+            da = min(da, abs(da - 3.141592653589793))
+            if ta != tb or swa != swb or not da <= 0.008726646259971648:  # half a degree
                 sensitive.add((s, k))
-                print(f"stream {s} call {k}: column-major (reference) {ta} {swa}   {name} {tb} {swb}")
+                print(f"stream {s} call {k}: column-major (reference) {ta} {swa} angle {aa!r}   {name} {tb} {swb} angle {ab!r}")
     print(f"{len(sensitive)} of {len(a)} calls depend on the summation order: {sorted(sensitive)}")

@@ -127,6 +127,12 @@ def camshift_case():
                 wa, ga = float(to["angle"]), float(g["angle"])
                 d = 0.0 if (np.isnan(wa) and np.isnan(ga)) else abs(ga - wa)
                 d = min(d, abs(d - np.pi))
+                # a LOST object (0 x 0 on both sides) has no orientation: a, b, c of camshift.js:230-245 are rounding noise of the sums there and
+                # atan2 of noise is anything — the reference's own loop returns 0 or pi / 2 for such calls depending on the summation order
+                # (tools/cpu_cs_order_check.py).  Counted, not compared.
+                if float(to["width"]) == 0.0 and float(to["height"]) == 0.0 and float(g["width"]) == 0.0 and float(g["height"]) == 0.0 and not d <= np.deg2rad(0.5):
+                    STATS["lost_angle"] = STATS.get("lost_angle", 0) + 1
+                    d = 0.0
                 calls += 1
                 STATS["cs_exact"] += int(exact)
                 if d <= np.deg2rad(0.5):  # (a call out of tolerance is reported on its own below)
@@ -177,6 +183,8 @@ def main():
     print(f"soak seed {SEED}, {time.time() - t0:.0f} s: detect {nd} cases / {len(sizes)} geometries / {nf} frames / {nh} raw hits (positions + confidence bits) "
           f"and {npl} pyramid planes vs oracle; camshift {ncs} cases / {ncalls} track() calls, {STATS['cs_exact']} exact in window, x, y, width, height "
           f"(the rest within +-1 px: {STATS['cs_not_exact'][:6]}), max |angle difference| {STATS['angle_max']:.3e} rad")
+    if STATS.get("lost_angle"):
+        print(f"{STATS['lost_angle']} call(s) returned a lost (0 x 0) object whose angle differs from the oracle's: the angle of a 0 x 0 object is atan2 of rounding noise, not compared")
     for rec in STATS.get("cs_ties", []):
         print(f"order-sensitive tie (the reference's own loop returns another object in another summation order; dumped to gpurun_out/): {rec}")
     if fails:
